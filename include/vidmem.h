@@ -1,0 +1,162 @@
+/* vidmem.h - C ABI of libvidmem.so: the MI355X (gfx950) replacement for the frame-embedding +
+ * cosine/top-k hot path of VidGraph (RaphaelHaddad/Real-Time-Brain-Inspired-Video-Memory).
+ *
+ * The reference is pure Python and has no FFI; each entry point below names the reference call site whose
+ * arithmetic it replaces (paths relative to the reference repository root).  INTEGRATION.md shows the ctypes
+ * stubs a maintainer adds at those call sites.
+ *
+ * Conventions
+ *   - plain C: opaque handles, raw pointers, sizes.  No torch / HIP types (streams travel as void*).
+ *   - every data pointer is a DEVICE pointer unless the parameter name ends in _host.
+ *   - return 0 = VM_OK, negative = vm_status; text via vm_last_error(ctx).
+ *   - the caller owns every buffer; the library allocates only inside vm_*_create (freed by *_destroy).
+ *   - vm_preprocess / vm_encode / vm_memory_append / vm_topk_* enqueue work on the given stream and return:
+ *     no hidden synchronisation, no allocation, no host threads -> capturable into a hipGraph.
+ *   - calls on one handle must be stream-ordered by the caller.
+ */
+#ifndef VIDMEM_H
+#define VIDMEM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vm_ctx vm_ctx;
+typedef struct vm_encoder vm_encoder;
+typedef struct vm_memory vm_memory;
+
+enum vm_status {
+    VM_OK = 0,
+    VM_ERR_INVALID = -1,     /* bad argument (shape / dtype / null) - the Python adapters raise on this   */
+    VM_ERR_HIP = -2,         /* a HIP runtime call failed                                                */
+    VM_ERR_NOMEM = -3,       /* device allocation failed or caller workspace too small                   */
+    VM_ERR_UNSUPPORTED = -4, /* shape outside what the kernels are built for                             */
+    VM_ERR_NO_DEVICE = -5    /* no gfx950 device visible                                                 */
+};
+enum vm_dtype { VM_F16 = 0, VM_BF16 = 1 };
+enum vm_act { VM_ACT_GELU = 0, VM_ACT_QUICK_GELU = 1 };
+enum vm_layout { VM_LAYOUT_CHW = 0, VM_LAYOUT_PATCHES = 1 };
+/* Neo4j's vector.similarity.cosine (retriever_hybrid.py:296) is third-party and unpinned: the score mapping is
+ * an explicit parameter instead of a guess.  RAW = cosine, UNIT_INTERVAL = (1 + cosine) / 2. */
+enum vm_score_mode { VM_SCORE_RAW = 0, VM_SCORE_UNIT_INTERVAL = 1 };
+
+/* ---- context ------------------------------------------------------------------------------------------ */
+int vm_init(int device, vm_ctx **out);
+void vm_destroy(vm_ctx *ctx);
+const char *vm_last_error(vm_ctx *ctx);
+/* ABI version of this header (bumped on any signature change). */
+int vm_abi_version(void);
+
+/* ---- frame preprocessing ------------------------------------------------------------------------------
+ * Replaces the CPU frame handling between cv2.VideoCapture.read and the VLM request:
+ * src/pipeline/vlm_extractor.py:110-128 (BGR uint8 HWC frames; JPEG/base64 is NOT reproduced).
+ * frames: uint8 [B,H,W,3] BGR.  Bilinear resize (half-pixel centres, edge clamp, no antialias) to
+ * out_S x out_S, BGR->RGB, x*(1/(255*std)) - mean/std, cast to `dtype`.
+ * layout CHW    : out [B,3,S,S]
+ * layout PATCHES: out [B,(S/patch)^2,k_pad], k index = c*patch*patch + py*patch + px, zero-padded to k_pad
+ *                 (the patch-embed GEMM's A operand; k_pad = vm_encoder_patch_k(enc)). */
+int vm_preprocess(vm_ctx *ctx, const uint8_t *frames_hwc_bgr, int B, int H, int W, const float mean_host[3],
+                  const float std_host[3], int out_S, int dtype, int layout, int patch, int k_pad, void *out,
+                  void *stream);
+
+/* ---- vision encoder -----------------------------------------------------------------------------------
+ * Replaces the remote model behind VLMExtractor._call_vlm_api (src/pipeline/vlm_extractor.py:130-185) and
+ * behind OpenAIEmbeddings.aembed_query (src/components/neo4j_handler.py:27-31,333;
+ * src/components/pre_llm_injector.py:207-221): frames -> one embedding vector each. */
+typedef struct vm_encoder_desc {
+    int image;      /* input side, 224 or 336                          */
+    int patch;      /* 16 or 14                                        */
+    int hidden;     /* 768 / 1024                                      */
+    int layers;     /* 12 / 24                                         */
+    int heads;      /* 12 / 16 (head dim must be 64)                   */
+    int mlp;        /* 3072 / 4096                                     */
+    int act;        /* vm_act                                          */
+    int pre_ln;     /* 1: LayerNorm after the embeddings (CLIP)        */
+    int patch_bias; /* 1: patch-embed conv has a bias (ViT)            */
+    int proj_dim;   /* 0: none, else output projection rows            */
+    int dtype;      /* vm_dtype of GEMM operands and of the output     */
+    float ln_eps;
+} vm_encoder_desc;
+
+/* weights_host: array of DEVICE pointers, in this order (n = 9 + 12*layers):
+ *   0 patch_w [hidden, k_pad] dtype (k = c*p*p+py*p+px, zero-padded)   1 patch_b [hidden] f32
+ *   2 cls [hidden] f32        3 pos [tokens, hidden] f32
+ *   4 pre_ln_g  5 pre_ln_b  (f32 [hidden]; ignored unless pre_ln)
+ *   6 ln_g  7 ln_b (final LayerNorm, f32)      8 proj_w [proj_dim, hidden] dtype (ignored if proj_dim == 0)
+ *   then per layer l, base = 9 + 12*l:
+ *   +0 ln1_g +1 ln1_b (f32)  +2 qkv_w [3*hidden, hidden] dtype  +3 qkv_b [3*hidden] f32
+ *   +4 proj_w [hidden, hidden] dtype  +5 proj_b f32  +6 ln2_g +7 ln2_b (f32)
+ *   +8 fc1_w [mlp, hidden] dtype  +9 fc1_b f32  +10 fc2_w [hidden, mlp] dtype  +11 fc2_b f32
+ * All matrices are row-major [out_features][in_features] (torch.nn.Linear layout).  The library copies them
+ * (device-to-device) during create; the caller may free its copies afterwards. */
+int vm_encoder_create(vm_ctx *ctx, const vm_encoder_desc *desc, const void *const *weights_host, int n_weights,
+                      vm_encoder **out);
+void vm_encoder_destroy(vm_encoder *enc);
+int vm_encoder_tokens(const vm_encoder *enc);    /* patches + 1                        */
+int vm_encoder_patch_k(const vm_encoder *enc);   /* 3*patch*patch rounded up to 64     */
+int vm_encoder_out_dim(const vm_encoder *enc);   /* proj_dim ? proj_dim : hidden       */
+size_t vm_encode_workspace_bytes(const vm_encoder *enc, int B);
+/* patches: [B, tokens-1, patch_k] dtype (vm_preprocess, PATCHES layout).  out_emb: [B, out_dim] dtype.
+ * l2_normalise: divide each embedding by its L2 norm (fp32) before the cast. */
+int vm_encode(vm_encoder *enc, const void *patches, int B, void *out_emb, int l2_normalise, void *workspace,
+              size_t workspace_bytes, void *stream);
+
+/* ---- embedding memory ---------------------------------------------------------------------------------
+ * Replaces the Chunk.embedding store: append = src/components/neo4j_handler.py:229-242
+ * (MERGE ... SET c.embedding), bulk read-back = src/components/pre_llm_injector.py:390-412.
+ * Rows are kept resident in HBM as [capacity, D] dtype, plus per row an exact fp64 norm and an fp32 reciprocal
+ * norm.  Row id = append order (0,1,2,...).  ring=1: after `capacity` rows the oldest are overwritten; ids keep
+ * counting, only the newest `capacity` ids are searchable. */
+int vm_memory_create(vm_ctx *ctx, int64_t capacity_rows, int D, int dtype, int ring, vm_memory **out);
+void vm_memory_destroy(vm_memory *mem);
+/* rows: [B, D] dtype.  *out_first_row_host (optional) receives the id of the first appended row. */
+int vm_memory_append(vm_memory *mem, const void *rows, int B, int64_t *out_first_row_host, void *stream);
+int64_t vm_memory_size(const vm_memory *mem);  /* rows appended so far (host mirror)                      */
+int64_t vm_memory_capacity(const vm_memory *mem);
+int vm_memory_dim(const vm_memory *mem);
+int vm_memory_reset(vm_memory *mem, void *stream);
+const void *vm_memory_rows(const vm_memory *mem); /* device pointer to the [capacity, D] row store          */
+
+/* ---- cosine top-k over the memory ---------------------------------------------------------------------
+ * Replaces PreLLMInjector._calculate_batch_similarities + _cosine_similarity
+ * (src/components/pre_llm_injector.py:346-388) and the Cypher scan of HybridRetriever._vector_search_chunks
+ * (src/pipeline/retriever_hybrid.py:293-306).
+ *
+ * queries [Q, D] dtype.  For every query: score each stored row with the reference cosine, order by
+ * (score descending, row id ascending) - Python's stable sort over memory order - and keep the first k.
+ * out_scores [Q,k] are the reference's fp64 values BIT FOR BIT (sequential fp64 sums over the stored 16-bit
+ * values); out_rows [Q,k] int64 row ids, -1 padded (scores 0.0 padded).
+ *   global row id written = row_id * row_stride + row_offset   (row-sharded memory; use 1, 0 on one GPU)
+ *   use_min_score: keep only score > min_score (after the score_mode mapping).
+ * Two-stage: an fp32 MFMA scan keeps k+slack candidates per query, which are re-scored exactly.  A query whose
+ * result cannot be PROVEN equal to the exhaustive answer (fp32 error bound vs the gap to the best rejected
+ * row) is counted in *out_uncertified (device int32, may be NULL); run vm_topk_cosine_exact for those. */
+size_t vm_topk_workspace_bytes(const vm_memory *mem, int Q, int k);
+int vm_topk_cosine(vm_memory *mem, const void *queries, int Q, int k, int use_min_score, double min_score,
+                   int score_mode, int64_t row_stride, int64_t row_offset, double *out_scores,
+                   int64_t *out_rows, int32_t *out_uncertified, void *workspace, size_t workspace_bytes,
+                   void *stream);
+/* Exhaustive fp64 version of the same contract (every pair scored exactly; slow, always exact). */
+size_t vm_topk_exact_workspace_bytes(const vm_memory *mem, int Q, int k);
+int vm_topk_cosine_exact(vm_memory *mem, const void *queries, int Q, int k, int use_min_score,
+                         double min_score, int score_mode, int64_t row_stride, int64_t row_offset,
+                         double *out_scores, int64_t *out_rows, void *workspace, size_t workspace_bytes,
+                         void *stream);
+/* All-pairs exact cosine, out [Q, S] fp64: the post-compression filter of
+ * src/pipeline/retriever_hybrid.py:494-504 (query vs segment embeddings) and a checker for the scan.
+ * rows [S, D] dtype need not live in a vm_memory. */
+int vm_cosine_exact(vm_ctx *ctx, const void *queries, int Q, const void *rows, int64_t S, int D, int dtype,
+                    double *out, void *stream);
+/* Merge `parts` per-shard results (each [Q,k], sorted as above, -1 padded) into the global top-k:
+ * the step after the RCCL all-gather (and the cross-query max-merge input of pre_llm_injector.py:238-249).
+ * scores [parts,Q,k] fp64, rows [parts,Q,k] int64. */
+int vm_topk_merge(vm_ctx *ctx, const double *scores, const int64_t *rows, int parts, int Q, int k,
+                  double *out_scores, int64_t *out_rows, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIDMEM_H */

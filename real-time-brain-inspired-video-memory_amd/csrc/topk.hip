@@ -1,0 +1,546 @@
+// Cosine top-k over the resident embedding memory.
+//
+// Replaces, arithmetic included:
+//   src/components/pre_llm_injector.py:346-388  (_calculate_batch_similarities + _cosine_similarity)
+//   src/pipeline/retriever_hybrid.py:293-306    (the Cypher cosine scan / ORDER BY / LIMIT)
+//
+// Two stages.
+//   scan     : HBM-bound pass over the [n, D] 16-bit rows.  Each wave takes 16-row tiles; the row tile is the
+//              MFMA A operand (loaded straight into registers: every row is read exactly once), the query tile
+//              is the B operand (staged once per block in LDS, chunk-swizzled so the ds_read_b128 fragment reads
+//              are conflict-free).  fp32 scores * 1/||row||; every lane keeps a sorted list of its KL best
+//              (score desc, age-order asc) in registers; lists are merged across the 4 lane groups by shuffles
+//              and across waves by rank counting in LDS -> one sorted list of KL per (block, query).
+//   finalize : one block per query.  KL-th best list head = threshold; the <= KL*KL entries above it are ranked
+//              in LDS; the best KL are re-scored EXACTLY as the reference does (fp64, one rounding per product
+//              and per partial sum, left to right; norms likewise; dot / (nq * nm)), ordered by
+//              (exact score desc, row id asc) == Python's stable sort over memory order, filtered and written.
+//              The result is certified when the exact k-th score clears the best rejected fp32 score by more
+//              than the fp32 error bound; otherwise the query is counted in *uncertified and the caller runs
+//              the exhaustive kernel (topk_exact.hip).
+#include "vm_internal.h"
+
+#include <climits>
+
+namespace {
+
+constexpr int SCAN_THREADS = 512;
+constexpr int FIN_THREADS = 256;
+constexpr int MAX_BLOCKS = 512;  // lists per query the finalize kernel accepts
+
+__device__ __forceinline__ bool better(float s1, int o1, float s2, int o2) {
+    return s1 > s2 || (s1 == s2 && o1 < o2);
+}
+
+// Sorted (best first) register list, branch-free insert with compile-time indices only.
+template <int KL>
+__device__ __forceinline__ void list_insert(float (&ls)[KL], int (&lo)[KL], float s, int o) {
+#pragma unroll
+    for (int i = KL - 1; i > 0; --i) {
+        const bool shift = better(s, o, ls[i - 1], lo[i - 1]);  // new entry lands above i: i takes i-1
+        const bool here = better(s, o, ls[i], lo[i]);           // new entry lands at or above i
+        ls[i] = shift ? ls[i - 1] : (here ? s : ls[i]);
+        lo[i] = shift ? lo[i - 1] : (here ? o : lo[i]);
+    }
+    const bool here0 = better(s, o, ls[0], lo[0]);
+    ls[0] = here0 ? s : ls[0];
+    lo[0] = here0 ? o : lo[0];
+}
+
+struct RingView {
+    int64_t n;     // searchable rows
+    int64_t head;  // physical slot of the oldest row
+    int64_t base;  // row id of the oldest row
+    int64_t cap;
+};
+__device__ __forceinline__ RingView ring_view(int64_t total, int64_t cap, int ring) {
+    RingView v;
+    v.cap = cap;
+    if (ring && total > cap) {
+        v.n = cap;
+        v.head = total % cap;
+        v.base = total - cap;
+    } else {
+        v.n = total < cap ? total : cap;
+        v.head = 0;
+        v.base = 0;
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// scan
+// ---------------------------------------------------------------------------------------------------------
+// LDS: [QT*16][D] query elements (chunk-swizzled); reused afterwards as the merge area [waves][QT*16][KL] {f32,i32}.
+template <int DT, int KL, int QT>
+__global__ void __launch_bounds__(SCAN_THREADS)
+    topk_scan_kernel(const uint16_t *__restrict__ mem, const float *__restrict__ rnorm,
+                     const uint16_t *__restrict__ queries, const int64_t *__restrict__ d_total, int64_t cap,
+                     int ring, int D, int Q, int q_pad, float *__restrict__ part_s, int *__restrict__ part_o) {
+    using E = vm_elem<DT>;
+    using vec8 = typename E::vec8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint4 *qlds = reinterpret_cast<uint4 *>(smem);
+    const int chunks = D / 8;  // 16-byte chunks per row; multiple of 16
+    // the merge area reuses the query area once the scan loop is done (barrier in between)
+    float *ms = reinterpret_cast<float *>(smem);
+    const int nw = SCAN_THREADS / 64;
+    int *mo = reinterpret_cast<int *>(ms + nw * QT * 16 * KL);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, h = lane >> 4;
+    const int q0 = blockIdx.y * (QT * 16);
+
+    // stage the query tile: chunk ci of query q sits at (ci & ~15) | ((ci ^ q) & 15)
+    for (int idx = tid; idx < QT * 16 * chunks; idx += SCAN_THREADS) {
+        const int q = idx / chunks, ci = idx - q * chunks;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (q0 + q < Q) v = reinterpret_cast<const uint4 *>(queries + (size_t)(q0 + q) * D)[ci];
+        qlds[q * chunks + ((ci & ~15) | ((ci ^ q) & 15))] = v;
+    }
+    __syncthreads();
+
+    float ls[QT][KL];
+    int lo[QT][KL];
+#pragma unroll
+    for (int t = 0; t < QT; ++t)
+#pragma unroll
+        for (int i = 0; i < KL; ++i) {
+            ls[t][i] = -INFINITY;
+            lo[t][i] = INT_MAX;
+        }
+
+    const RingView rv = ring_view(*d_total, cap, ring);
+    const int64_t ntiles = (rv.n + 15) / 16;
+    const int ksteps = D / 32;  // multiple of 4
+
+    for (int64_t tile = (int64_t)blockIdx.x * nw + wave; tile < ntiles; tile += (int64_t)gridDim.x * nw) {
+        int64_t row = tile * 16 + r16;
+        if (row > rv.n - 1) row = rv.n - 1;  // tail lanes re-read the last row; their scores are masked below
+        const uint4 *src = reinterpret_cast<const uint4 *>(mem + (size_t)row * D) + h;
+        f32x4 acc[QT];
+#pragma unroll
+        for (int t = 0; t < QT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s0 = 0; s0 < ksteps; s0 += 4) {
+            uint4 a[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] = src[(s0 + u) * 4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ci = h + 4 * (s0 + u);
+                const vec8 av = __builtin_bit_cast(vec8, a[u]);
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+                    const uint4 bq = qlds[(t * 16 + r16) * chunks + ((ci & ~15) | ((ci ^ r16) & 15))];
+                    acc[t] = E::mfma16(av, __builtin_bit_cast(vec8, bq), acc[t]);
+                }
+            }
+        }
+        // acc[t][j] = <row tile*16 + 4h + j , query q0 + 16t + r16>
+        const int64_t p0 = tile * 16 + 4 * h;
+        const float4 rn = *reinterpret_cast<const float4 *>(rnorm + p0);  // allocation is padded to 64 rows
+        const float rnv[4] = {rn.x, rn.y, rn.z, rn.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t p = p0 + j;
+            int64_t o64 = p - rv.head;
+            if (o64 < 0) o64 += rv.cap;
+            const int o = (int)o64;
+            const bool valid = p < rv.n;
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                const float s = valid ? acc[t][j] * rnv[j] : -INFINITY;
+                if (valid && better(s, o, ls[t][KL - 1], lo[t][KL - 1])) list_insert<KL>(ls[t], lo[t], s, o);
+            }
+        }
+    }
+
+    // merge the 4 lane groups of each query inside the wave (partners at lane ^ 16, lane ^ 32): half-cleaner
+    // against the partner's reversed list keeps the KL best of both (a bitonic sequence), then a bitonic merge
+    // network re-sorts it.  Static indices only, O(KL log KL) code.
+#pragma unroll
+    for (int step = 16; step <= 32; step <<= 1) {
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            float ps[KL];
+            int po[KL];
+#pragma unroll
+            for (int i = 0; i < KL; ++i) {
+                ps[i] = __shfl_xor(ls[t][KL - 1 - i], step, 64);
+                po[i] = __shfl_xor(lo[t][KL - 1 - i], step, 64);
+            }
+#pragma unroll
+            for (int i = 0; i < KL; ++i) {
+                const bool take = better(ps[i], po[i], ls[t][i], lo[t][i]);
+                ls[t][i] = take ? ps[i] : ls[t][i];
+                lo[t][i] = take ? po[i] : lo[t][i];
+            }
+#pragma unroll
+            for (int stride = KL / 2; stride > 0; stride >>= 1) {
+#pragma unroll
+                for (int i = 0; i < KL; ++i) {
+                    if ((i & stride) == 0) {
+                        const bool sw = better(ls[t][i + stride], lo[t][i + stride], ls[t][i], lo[t][i]);
+                        const float s_hi = sw ? ls[t][i + stride] : ls[t][i];
+                        const float s_lo = sw ? ls[t][i] : ls[t][i + stride];
+                        const int o_hi = sw ? lo[t][i + stride] : lo[t][i];
+                        const int o_lo = sw ? lo[t][i] : lo[t][i + stride];
+                        ls[t][i] = s_hi;
+                        ls[t][i + stride] = s_lo;
+                        lo[t][i] = o_hi;
+                        lo[t][i + stride] = o_lo;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();  // every wave is done reading the query tile: its LDS becomes the merge area
+    if (h == 0) {
+#pragma unroll
+        for (int t = 0; t < QT; ++t)
+#pragma unroll
+            for (int i = 0; i < KL; ++i) {
+                ms[((wave * QT + t) * 16 + r16) * KL + i] = ls[t][i];
+                mo[((wave * QT + t) * 16 + r16) * KL + i] = lo[t][i];
+            }
+    }
+    __syncthreads();
+    // cross-wave merge by rank counting: nw*KL candidates per query, strict order (score, order, candidate idx)
+    const int ncand = nw * KL;
+    for (int pq = wave; pq < QT * 16; pq += nw) {  // pq = t*16 + r
+        for (int c = lane; c < ncand; c += 64) {
+            const int cw = c / KL, ci = c - cw * KL;
+            const float s = ms[((cw * QT * 16) + pq) * KL + ci];
+            const int o = mo[((cw * QT * 16) + pq) * KL + ci];
+            int rank = 0;
+            for (int d = 0; d < ncand; ++d) {
+                const int dw = d / KL, di = d - dw * KL;
+                const float s2 = ms[((dw * QT * 16) + pq) * KL + di];
+                const int o2 = mo[((dw * QT * 16) + pq) * KL + di];
+                rank += (better(s2, o2, s, o) || (s2 == s && o2 == o && d < c)) ? 1 : 0;
+            }
+            if (rank < KL) {
+                const size_t dst = ((size_t)blockIdx.x * q_pad + q0 + pq) * KL + rank;
+                part_s[dst] = s;
+                part_o[dst] = o;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// finalize
+// ---------------------------------------------------------------------------------------------------------
+template <int DT, int KL>
+__global__ void __launch_bounds__(FIN_THREADS)
+    topk_finalize_kernel(const uint16_t *__restrict__ mem, const double *__restrict__ norm64,
+                         const uint16_t *__restrict__ queries, const int64_t *__restrict__ d_total, int64_t cap,
+                         int ring, int D, int q_pad, int nblk, const float *__restrict__ part_s,
+                         const int *__restrict__ part_o, int k, int use_min, double min_score, int score_mode,
+                         int64_t row_stride, int64_t row_offset, double *__restrict__ out_scores,
+                         int64_t *__restrict__ out_rows, int *__restrict__ uncertified) {
+    using E = vm_elem<DT>;
+    __shared__ float hs[MAX_BLOCKS];
+    __shared__ int ho[MAX_BLOCKS];
+    __shared__ int qual[KL];
+    __shared__ float cs[KL * KL];
+    __shared__ int co[KL * KL];
+    __shared__ float fs[KL];
+    __shared__ int fo[KL];
+    __shared__ double ex[KL];
+    __shared__ double qnorm_sh;
+    __shared__ int cnt, nqual;
+
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const RingView rv = ring_view(*d_total, cap, ring);
+
+    if (tid == 0) {
+        cnt = 0;
+        nqual = 0;
+    }
+    for (int b = tid; b < nblk; b += FIN_THREADS) {
+        hs[b] = part_s[((size_t)b * q_pad + q) * KL];
+        ho[b] = part_o[((size_t)b * q_pad + q) * KL];
+    }
+    if (tid < KL) {
+        fs[tid] = -INFINITY;
+        fo[tid] = INT_MAX;
+    }
+    __syncthreads();
+    // lists whose head ranks among the KL best heads can contain members of the global top KL
+    for (int b = tid; b < nblk; b += FIN_THREADS) {
+        const float s = hs[b];
+        const int o = ho[b];
+        int rank = 0;
+        for (int d = 0; d < nblk; ++d) rank += (better(hs[d], ho[d], s, o) || (hs[d] == s && ho[d] == o && d < b));
+        if (rank < KL && s > -INFINITY) qual[atomicAdd(&nqual, 1)] = b;
+    }
+    __syncthreads();
+    const int nq_lists = nqual;
+    for (int p = tid; p < nq_lists * KL; p += FIN_THREADS) {
+        const int b = qual[p / KL], e = p % KL;
+        const float s = part_s[((size_t)b * q_pad + q) * KL + e];
+        const int o = part_o[((size_t)b * q_pad + q) * KL + e];
+        if (s > -INFINITY) {
+            const int slot = atomicAdd(&cnt, 1);
+            cs[slot] = s;
+            co[slot] = o;
+        }
+    }
+    __syncthreads();
+    const int C = cnt;
+    for (int c = tid; c < C; c += FIN_THREADS) {
+        const float s = cs[c];
+        const int o = co[c];
+        int rank = 0;
+        for (int d = 0; d < C; ++d) rank += better(cs[d], co[d], s, o) ? 1 : 0;
+        if (rank < KL) {
+            fs[rank] = s;
+            fo[rank] = o;
+        }
+    }
+    __syncthreads();
+    const int nfin = C < KL ? C : KL;
+
+    // exact re-scoring: thread t < nfin takes candidate t; thread KL takes the query norm.
+    const uint16_t *qv = queries + (size_t)q * D;
+    if (tid < nfin) {
+        int64_t p = fo[tid] + rv.head;
+        if (p >= rv.cap) p -= rv.cap;
+        const uint16_t *mv = mem + (size_t)p * D;
+        double dot = 0.0;
+        for (int i = 0; i < D; i += 8) {
+            const uint4 a = *reinterpret_cast<const uint4 *>(qv + i);
+            const uint4 b = *reinterpret_cast<const uint4 *>(mv + i);
+            const uint16_t *ae = reinterpret_cast<const uint16_t *>(&a);
+            const uint16_t *be = reinterpret_cast<const uint16_t *>(&b);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                dot = __dadd_rn(dot, __dmul_rn(E::to_double(ae[j]), E::to_double(be[j])));
+        }
+        ex[tid] = dot;
+    } else if (tid == KL) {
+        double nq = 0.0;
+        for (int i = 0; i < D; i += 8) {
+            const uint4 a = *reinterpret_cast<const uint4 *>(qv + i);
+            const uint16_t *ae = reinterpret_cast<const uint16_t *>(&a);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const double x = E::to_double(ae[j]);
+                nq = __dadd_rn(nq, __dmul_rn(x, x));
+            }
+        }
+        qnorm_sh = __dsqrt_rn(nq);
+    }
+    __syncthreads();
+    const double qn = qnorm_sh;
+    if (tid < nfin) {
+        int64_t p = fo[tid] + rv.head;
+        if (p >= rv.cap) p -= rv.cap;
+        const double mn = norm64[p];
+        // src/components/pre_llm_injector.py:385-388
+        ex[tid] = (qn == 0.0 || mn == 0.0) ? 0.0 : __ddiv_rn(ex[tid], __dmul_rn(qn, mn));
+    }
+    if (tid < k) {
+        out_scores[(size_t)q * k + tid] = 0.0;
+        out_rows[(size_t)q * k + tid] = -1;
+    }
+    __syncthreads();
+    if (tid < nfin) {
+        const double e = ex[tid];
+        const int o = fo[tid];
+        int rank = 0;
+        for (int d = 0; d < nfin; ++d) rank += (ex[d] > e || (ex[d] == e && fo[d] < o)) ? 1 : 0;
+        const double shown = score_mode == VM_SCORE_UNIT_INTERVAL ? __ddiv_rn(__dadd_rn(1.0, e), 2.0) : e;
+        const bool pass = !use_min || shown > min_score;
+        if (rank < k && pass) {
+            out_scores[(size_t)q * k + rank] = shown;
+            out_rows[(size_t)q * k + rank] = (rv.base + o) * row_stride + row_offset;
+        }
+        // certification: is the exact k-th score provably above every row that never became a candidate?
+        const int kth = (k < nfin ? k : nfin) - 1;
+        if (rank == kth && uncertified) {
+            const bool all_rows_are_candidates = rv.n <= (int64_t)nfin;
+            if (!all_rows_are_candidates && qn != 0.0) {
+                const float bound_f32 = fs[KL - 1];  // best possible fp32 score of a rejected row (x 1/||q||)
+                const double eps = 2.0 * (double)(D + 8) * 5.9604644775390625e-08;  // 2*(D+8)*2^-24
+                const double reject = (double)bound_f32 / qn + eps;
+                if (!(e > reject)) atomicAdd(uncertified, 1);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// merge of per-shard results (after the RCCL all-gather): parts*k entries per query, rank counting
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    topk_merge_kernel(const double *__restrict__ scores, const int64_t *__restrict__ rows, int parts, int Q,
+                      int k, double *__restrict__ out_scores, int64_t *__restrict__ out_rows) {
+    const int q = blockIdx.x;
+    const int n = parts * k;
+    for (int i = threadIdx.x; i < k; i += blockDim.x) {
+        out_scores[(size_t)q * k + i] = 0.0;
+        out_rows[(size_t)q * k + i] = -1;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < n; c += blockDim.x) {
+        const int cp = c / k, ci = c - cp * k;
+        const double s = scores[((size_t)cp * Q + q) * k + ci];
+        const int64_t r = rows[((size_t)cp * Q + q) * k + ci];
+        if (r < 0) continue;
+        int rank = 0;
+        for (int d = 0; d < n; ++d) {
+            const int dp = d / k, di = d - dp * k;
+            const double s2 = scores[((size_t)dp * Q + q) * k + di];
+            const int64_t r2 = rows[((size_t)dp * Q + q) * k + di];
+            if (r2 < 0) continue;
+            rank += (s2 > s || (s2 == s && (r2 < r || (r2 == r && d < c)))) ? 1 : 0;
+        }
+        if (rank < k) {
+            out_scores[(size_t)q * k + rank] = s;
+            out_rows[(size_t)q * k + rank] = r;
+        }
+    }
+}
+
+struct ScanCfg {
+    int KL, QT;
+};
+ScanCfg pick_cfg(int Q, int k, int D) {
+    ScanCfg c;
+    c.KL = k + 2 <= 8 ? 8 : (k + 4 <= 16 ? 16 : (k + 6 <= 32 ? 32 : 64));
+    int qt_max = 64 / c.KL;  // QT*KL <= 64 list registers pairs per lane
+    if (qt_max > 4) qt_max = 4;
+    int need = (Q + 15) / 16;
+    c.QT = need >= 4 && qt_max >= 4 ? 4 : (need >= 2 && qt_max >= 2 ? 2 : 1);
+    while (c.QT > 1 && (size_t)c.QT * 16 * D * 2 > 144 * 1024) c.QT /= 2;  // query tile must fit in LDS
+    return c;
+}
+
+struct ScanPlan {
+    ScanCfg cfg;
+    int q_pad, qgroups, nblk;
+    size_t lds;
+    size_t part_bytes;
+};
+ScanPlan make_plan(const vm_memory *m, int Q, int k) {
+    ScanPlan p;
+    p.cfg = pick_cfg(Q, k, m->D);
+    const int qpg = p.cfg.QT * 16;
+    p.qgroups = (Q + qpg - 1) / qpg;
+    p.q_pad = p.qgroups * qpg;
+    const int nw = SCAN_THREADS / 64;
+    const int64_t ntiles = (m->cap + 15) / 16;
+    int64_t want = (ntiles + nw - 1) / nw;
+    const int per_cu = (p.cfg.QT * p.cfg.KL <= 32) ? 2 : 1;
+    int64_t lim = (int64_t)m->ctx->num_cus * per_cu;
+    if (lim > MAX_BLOCKS) lim = MAX_BLOCKS;
+    p.nblk = (int)(want < lim ? want : lim);
+    if (p.nblk < 1) p.nblk = 1;
+    const size_t lds_q = (size_t)qpg * m->D * 2, lds_m = (size_t)nw * qpg * p.cfg.KL * 8;
+    p.lds = lds_q > lds_m ? lds_q : lds_m;
+    p.part_bytes = vm_align_up((size_t)p.nblk * p.q_pad * p.cfg.KL * 4, 256);
+    return p;
+}
+
+template <int DT, int KL, int QT>
+int launch_scan(vm_memory *m, const ScanPlan &p, const void *queries, int Q, float *part_s, int *part_o,
+                hipStream_t st) {
+    auto kern = topk_scan_kernel<DT, KL, QT>;
+    if (p.lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)p.lds);
+        if (e != hipSuccess) return vm_fail(m->ctx, VM_ERR_HIP, "LDS opt-in %zu: %s", p.lds, hipGetErrorString(e));
+    }
+    dim3 grid(p.nblk, p.qgroups);
+    kern<<<grid, SCAN_THREADS, p.lds, st>>>(m->rows, m->rnorm32, (const uint16_t *)queries, m->d_total, m->cap,
+                                          m->ring, m->D, Q, p.q_pad, part_s, part_o);
+    VM_LAUNCH_CHECK(m->ctx);
+    return VM_OK;
+}
+
+template <int DT, int KL>
+int launch_scan_qt(vm_memory *m, const ScanPlan &p, const void *queries, int Q, float *part_s, int *part_o,
+                   hipStream_t st) {
+    if constexpr (KL <= 16) {
+        if (p.cfg.QT == 4) return launch_scan<DT, KL, 4>(m, p, queries, Q, part_s, part_o, st);
+    }
+    if constexpr (KL <= 32) {
+        if (p.cfg.QT == 2) return launch_scan<DT, KL, 2>(m, p, queries, Q, part_s, part_o, st);
+    }
+    return launch_scan<DT, KL, 1>(m, p, queries, Q, part_s, part_o, st);
+}
+
+template <int DT>
+int run_topk(vm_memory *m, const ScanPlan &p, const void *queries, int Q, int k, int use_min, double min_score,
+             int score_mode, int64_t row_stride, int64_t row_offset, double *out_scores, int64_t *out_rows,
+             int *uncertified, float *part_s, int *part_o, hipStream_t st) {
+    int rc;
+    switch (p.cfg.KL) {
+        case 8: rc = launch_scan_qt<DT, 8>(m, p, queries, Q, part_s, part_o, st); break;
+        case 16: rc = launch_scan_qt<DT, 16>(m, p, queries, Q, part_s, part_o, st); break;
+        case 32: rc = launch_scan_qt<DT, 32>(m, p, queries, Q, part_s, part_o, st); break;
+        default: rc = launch_scan_qt<DT, 64>(m, p, queries, Q, part_s, part_o, st); break;
+    }
+    if (rc != VM_OK) return rc;
+#define FIN(KLV)                                                                                           \
+    topk_finalize_kernel<DT, KLV><<<Q, FIN_THREADS, 0, st>>>(                                              \
+        m->rows, m->norm64, (const uint16_t *)queries, m->d_total, m->cap, m->ring, m->D, p.q_pad, p.nblk, \
+        part_s, part_o, k, use_min, min_score, score_mode, row_stride, row_offset, out_scores, out_rows,   \
+        uncertified)
+    switch (p.cfg.KL) {
+        case 8: FIN(8); break;
+        case 16: FIN(16); break;
+        case 32: FIN(32); break;
+        default: FIN(64); break;
+    }
+#undef FIN
+    VM_LAUNCH_CHECK(m->ctx);
+    return VM_OK;
+}
+
+}  // namespace
+
+extern "C" size_t vm_topk_workspace_bytes(const vm_memory *m, int Q, int k) {
+    if (!m || Q <= 0 || k <= 0 || k > 58) return 0;
+    const ScanPlan p = make_plan(m, Q, k);
+    return 2 * p.part_bytes + 256;
+}
+
+extern "C" int vm_topk_cosine(vm_memory *m, const void *queries, int Q, int k, int use_min_score,
+                              double min_score, int score_mode, int64_t row_stride, int64_t row_offset,
+                              double *out_scores, int64_t *out_rows, int32_t *out_uncertified, void *workspace,
+                              size_t workspace_bytes, void *stream) {
+    if (!m) return VM_ERR_INVALID;
+    vm_ctx *ctx = m->ctx;
+    if (!queries || !out_scores || !out_rows || Q <= 0 || k <= 0)
+        return vm_fail(ctx, VM_ERR_INVALID, "vm_topk_cosine: bad arguments (Q=%d k=%d)", Q, k);
+    if (k > 58)
+        return vm_fail(ctx, VM_ERR_UNSUPPORTED, "vm_topk_cosine: k=%d > 58; use vm_topk_cosine_exact", k);
+    if (score_mode != VM_SCORE_RAW && score_mode != VM_SCORE_UNIT_INTERVAL)
+        return vm_fail(ctx, VM_ERR_INVALID, "bad score_mode %d", score_mode);
+    const ScanPlan p = make_plan(m, Q, k);
+    if (!workspace || workspace_bytes < 2 * p.part_bytes)
+        return vm_fail(ctx, VM_ERR_NOMEM, "vm_topk_cosine: workspace %zu < %zu", workspace_bytes,
+                       2 * p.part_bytes);
+    if (((uintptr_t)workspace & 15) || ((uintptr_t)queries & 15))
+        return vm_fail(ctx, VM_ERR_INVALID, "vm_topk_cosine: pointers must be 16-byte aligned");
+    float *part_s = (float *)workspace;
+    int *part_o = (int *)((char *)workspace + p.part_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    if (m->dtype == VM_F16)
+        return run_topk<VM_F16>(m, p, queries, Q, k, use_min_score, min_score, score_mode, row_stride,
+                                row_offset, out_scores, out_rows, out_uncertified, part_s, part_o, st);
+    return run_topk<VM_BF16>(m, p, queries, Q, k, use_min_score, min_score, score_mode, row_stride, row_offset,
+                             out_scores, out_rows, out_uncertified, part_s, part_o, st);
+}
+
+extern "C" int vm_topk_merge(vm_ctx *ctx, const double *scores, const int64_t *rows, int parts, int Q, int k,
+                             double *out_scores, int64_t *out_rows, void *stream) {
+    if (!ctx || !scores || !rows || !out_scores || !out_rows || parts <= 0 || Q <= 0 || k <= 0)
+        return vm_fail(ctx, VM_ERR_INVALID, "vm_topk_merge: bad arguments");
+    topk_merge_kernel<<<Q, 256, 0, (hipStream_t)stream>>>(scores, rows, parts, Q, k, out_scores, out_rows);
+    VM_LAUNCH_CHECK(ctx);
+    return VM_OK;
+}

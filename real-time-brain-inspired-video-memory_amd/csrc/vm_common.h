@@ -1,0 +1,96 @@
+// Internal definitions shared by the libvidmem translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/vidmem.h"
+
+struct vm_ctx {
+    int device;
+    int num_cus;
+    char err[512];
+};
+
+inline int vm_fail(vm_ctx *ctx, int code, const char *fmt, ...) {
+    if (ctx) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+#define VM_HIP(ctx, call)                                                                              \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return vm_fail((ctx), VM_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),   \
+                           __FILE__, __LINE__);                                                        \
+    } while (0)
+
+#define VM_LAUNCH_CHECK(ctx)                                                                           \
+    do {                                                                                               \
+        hipError_t e_ = hipGetLastError();                                                             \
+        if (e_ != hipSuccess)                                                                          \
+            return vm_fail((ctx), VM_ERR_HIP, "kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), \
+                           __FILE__, __LINE__);                                                        \
+    } while (0)
+
+static inline size_t vm_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- 16-bit float helpers (device) ------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int DT>
+struct vm_elem;  // DT = VM_F16 / VM_BF16
+template <>
+struct vm_elem<VM_F16> {
+    using vec8 = f16x8;
+    static __device__ __forceinline__ float to_float(uint16_t b) {
+        _Float16 h;
+        __builtin_memcpy(&h, &b, 2);
+        return (float)h;
+    }
+    static __device__ __forceinline__ double to_double(uint16_t b) { return (double)to_float(b); }
+    static __device__ __forceinline__ uint16_t from_float(float f) {
+        _Float16 h = (_Float16)f;  // round-to-nearest-even
+        uint16_t b;
+        __builtin_memcpy(&b, &h, 2);
+        return b;
+    }
+    static __device__ __forceinline__ f32x4 mfma16(vec8 a, vec8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x16 mfma32(vec8 a, vec8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+template <>
+struct vm_elem<VM_BF16> {
+    using vec8 = bf16x8;
+    static __device__ __forceinline__ float to_float(uint16_t b) {
+        uint32_t u = ((uint32_t)b) << 16;
+        return __builtin_bit_cast(float, u);
+    }
+    static __device__ __forceinline__ double to_double(uint16_t b) { return (double)to_float(b); }
+    static __device__ __forceinline__ uint16_t from_float(float f) {
+        __bf16 h = (__bf16)f;  // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+        uint16_t b;
+        __builtin_memcpy(&b, &h, 2);
+        return b;
+    }
+    static __device__ __forceinline__ f32x4 mfma16(vec8 a, vec8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x16 mfma32(vec8 a, vec8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};

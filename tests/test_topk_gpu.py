@@ -1,0 +1,183 @@
+"""GPU parity: libvidmem's cosine top-k (through the C ABI) against the oracle and the reference-derived goldens.
+
+Bar: rows bit-identical, scores bit-identical fp64 (the kernel re-scores its candidates with the reference's own
+sequence of roundings).  Sizes: goldens (<= 4096 rows), a 100k-row seeded case against the C oracle, and 1M-row
+size-independent properties.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cref
+from oracle import similarity_ref as S
+from tests.golden.make_similarity_golden import CASES, make_inputs
+
+pytestmark = pytest.mark.gpu
+
+TD = {"f16": torch.float16, "bf16": torch.bfloat16}
+
+
+def _mem(case_or_dtype, capacity, dim, ring=False):
+    from vidmem.memory import EmbeddingMemory
+    return EmbeddingMemory(capacity, dim, dtype=case_or_dtype, ring=ring)
+
+
+def _bits(t: torch.Tensor) -> np.ndarray:
+    return t.contiguous().view(torch.int16).cpu().numpy().view(np.uint16)
+
+
+@pytest.fixture(scope="module")
+def golden(golden_dir):
+    return np.load(os.path.join(golden_dir, "similarity_golden.npz"))
+
+
+@pytest.mark.parametrize("exact", [False, True], ids=["scan", "exhaustive"])
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_golden_cases_bit_exact(case, exact, golden):
+    q, m = make_inputs(case)
+    mem = _mem(case["dtype"], max(case["M"], 16), case["D"])
+    mem.append(torch.tensor(m, dtype=torch.float64))
+    scores, rows = mem.topk(torch.tensor(q, dtype=torch.float64), case["k"], exact=exact)
+    n = case["name"]
+    assert np.array_equal(rows.cpu().numpy(), golden[n + "/rows"])
+    assert np.array_equal(scores.cpu().numpy(), golden[n + "/scores"])
+    if not exact:
+        assert mem.last_uncertified is not None
+
+
+def test_all_pairs_exact_matches_c_oracle():
+    rng = np.random.default_rng(5)
+    for dtype, D in (("f16", 768), ("bf16", 1024)):
+        m = torch.tensor(rng.standard_normal((1000, D)) * 0.7, dtype=torch.float32).to(TD[dtype])
+        q = torch.tensor(rng.standard_normal((9, D)), dtype=torch.float32).to(TD[dtype])
+        m[17] = 0
+        q[3] = 0
+        mem = _mem(dtype, 16, D)
+        got = mem.cosine_exact(q.cuda(), m.cuda()).cpu().numpy()
+        want = cref.cosine_matrix(_bits(q), _bits(m), dtype=dtype)
+        assert np.array_equal(got, want)  # bit for bit, including the zero-norm guards
+
+
+def test_threshold_and_score_mode():
+    case = CASES[0]
+    q, m = make_inputs(case)
+    mem = _mem("f16", case["M"], case["D"])
+    mem.append(torch.tensor(m, dtype=torch.float64))
+    qt = torch.tensor(q, dtype=torch.float64)
+    for mode in (S.SCORE_RAW, S.SCORE_UNIT_INTERVAL):
+        for thr in (0.3, 0.52, 0.9):
+            want_r, want_s = S.batch_topk_np(q, m, 8, min_score=thr, score_mode=mode)
+            for exact in (False, True):
+                s, r = mem.topk(qt, 8, min_score=thr, score_mode=mode, exact=exact)
+                assert np.array_equal(r.cpu().numpy(), want_r), (mode, thr, exact)
+                assert np.array_equal(s.cpu().numpy(), want_s), (mode, thr, exact)
+
+
+@pytest.mark.parametrize("M,Q,k", [(0, 3, 5), (1, 1, 1), (5, 2, 8), (17, 17, 3), (33, 65, 12), (300, 130, 26),
+                                   (200, 4, 40)])
+def test_ragged_shapes(M, Q, k):
+    rng = np.random.default_rng(M * 1000 + Q)
+    D = 256
+    m = torch.tensor(rng.standard_normal((max(M, 1), D)), dtype=torch.float32).to(torch.float16)[:M]
+    q = torch.tensor(rng.standard_normal((Q, D)), dtype=torch.float32).to(torch.float16)
+    mem = _mem("f16", max(M, 16), D)
+    if M:
+        mem.append(m)
+    s, r = mem.topk(q, k)
+    want_r, want_s = cref.cosine_topk(_bits(q), _bits(m) if M else np.zeros((0, D), np.uint16), k, dtype="f16")
+    assert np.array_equal(r.cpu().numpy(), want_r)
+    assert np.array_equal(s.cpu().numpy(), want_s)
+
+
+def test_ring_memory_overwrites_oldest():
+    rng = np.random.default_rng(11)
+    D, cap = 256, 96
+    mem = _mem("f16", cap, D, ring=True)
+    allrows = torch.tensor(rng.standard_normal((250, D)), dtype=torch.float32).to(torch.float16)
+    q = torch.tensor(rng.standard_normal((5, D)), dtype=torch.float32).to(torch.float16)
+    done = 0
+    for step in (40, 56, 30, 64, 60):  # crosses the wrap point several times
+        first = mem.append(allrows[done:done + step])
+        assert first == done
+        done += step
+        lo = max(0, done - cap)
+        want_r, want_s = cref.cosine_topk(_bits(q), _bits(allrows[lo:done]), 6, dtype="f16")
+        want_r = np.where(want_r >= 0, want_r + lo, -1)
+        for exact in (False, True):
+            s, r = mem.topk(q, 6, exact=exact)
+            assert np.array_equal(r.cpu().numpy(), want_r), (done, exact)
+            assert np.array_equal(s.cpu().numpy(), want_s), (done, exact)
+
+
+def test_many_exact_ties_fall_back_to_exhaustive():
+    # 40 identical rows: more ties than candidate slots -> the scan must refuse to certify, the wrapper must
+    # still return the reference answer (lowest row ids first).
+    rng = np.random.default_rng(3)
+    D = 256
+    base = torch.tensor(rng.standard_normal((1, D)), dtype=torch.float32).to(torch.float16)
+    m = torch.tensor(rng.standard_normal((500, D)), dtype=torch.float32).to(torch.float16)
+    m[100:140] = base
+    mem = _mem("f16", 512, D)
+    mem.append(m)
+    s, r = mem.topk(base, 10)
+    assert r.cpu().numpy().tolist() == [list(range(100, 110))]
+    assert mem.last_uncertified == 1
+    want_r, want_s = cref.cosine_topk(_bits(base), _bits(m), 10, dtype="f16")
+    assert np.array_equal(s.cpu().numpy(), want_s)
+
+
+def test_100k_rows_against_c_oracle():
+    from vidmem import synthetic as syn
+    D, M, Q, k = 768, 100_000, 16, 10
+    m = torch.from_numpy(syn.unit_rows(7, "memory100k", M, D)).to(torch.float16)
+    q = torch.from_numpy(syn.unit_rows(11, "queries100k", Q, D)).to(torch.float16)
+    q[:4] = (0.5 * m[[5, 77_777, 99_999, 31_415]].float() + 0.5 * q[:4].float()).to(torch.float16)
+    m[60_000] = m[5]  # an exact duplicate far away: tie broken by row id
+    mem = _mem("f16", M, D)
+    for lo in range(0, M, 25_000):
+        mem.append(m[lo:lo + 25_000])
+    s, r = mem.topk(q, k)
+    assert mem.last_uncertified == 0
+    want_r, want_s = cref.cosine_topk(_bits(q), _bits(m), k, dtype="f16")
+    assert np.array_equal(r.cpu().numpy(), want_r)
+    assert np.array_equal(s.cpu().numpy(), want_s)
+
+
+def test_full_size_properties_1m_rows():
+    """BASELINE metric size (1M x 768): size-independent properties instead of an oracle pass."""
+    D, M, Q, k = 768, 1_000_000, 16, 10
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    m = torch.randn((M, D), generator=g, device="cuda", dtype=torch.float32)
+    m = (m / m.norm(dim=1, keepdim=True)).to(torch.float16)
+    q = torch.randn((Q, D), generator=g, device="cuda", dtype=torch.float32).to(torch.float16)
+    planted = [3, 500_000, 999_999, 123_456]
+    for i, row in enumerate(planted):
+        q[i] = m[row]  # a stored row queried with itself must come first with score == 1 (to fp64 rounding)
+    from vidmem.memory import EmbeddingMemory, topk_merge
+    mem = EmbeddingMemory(M, D, "f16")
+    mem.append(m)
+    s, r = mem.topk(q, k)
+    assert mem.last_uncertified == 0
+    s_np, r_np = s.cpu().numpy(), r.cpu().numpy()
+    for i, row in enumerate(planted):
+        assert r_np[i, 0] == row and abs(s_np[i, 0] - 1.0) < 1e-12
+    assert (np.diff(s_np, axis=1) <= 0).all() and (r_np >= 0).all()
+    for i in range(Q):
+        assert len(set(r_np[i].tolist())) == k
+    # returned scores are the exact reference cosines of the returned rows
+    ex = mem.cosine_exact(q[:2], m[r[0]]).cpu().numpy()
+    assert np.array_equal(ex[0], s_np[0])
+    # sharding invariance: top-k(whole) == merge(top-k(halves)) with global row ids
+    halves = []
+    for part in range(2):
+        hm = EmbeddingMemory(M // 2, D, "f16")
+        hm.append(m[part::2])
+        halves.append(hm.topk(q, k, row_stride=2, row_offset=part))
+        hm.close()
+    ms, mr = topk_merge(mem.ctx, torch.stack([h[0] for h in halves]), torch.stack([h[1] for h in halves]))
+    assert np.array_equal(mr.cpu().numpy(), r_np) and np.array_equal(ms.cpu().numpy(), s_np)
+    # and the exhaustive kernel agrees on one query
+    s2, r2 = mem.topk(q[5:6], k, exact=True)
+    assert np.array_equal(r2.cpu().numpy(), r_np[5:6]) and np.array_equal(s2.cpu().numpy(), s_np[5:6])
