@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py - the hot path of BASELINE.json on N MI355X GPUs of one node.
+
+One "step" = one pass of the hot path over one batch of synthetic frames, per GPU:
+    uint8 BGR frames (resident in HBM) -> preprocess -> ViT-B/16 encoder (fp16) -> L2-normalised embeddings
+    -> [N>1: RCCL all-gather of the step's query embeddings] -> cosine top-10 of every query over the local
+    100k x 768 memory shard -> [N>1: RCCL all-gather of the per-shard candidates + merge] -> append the new
+    embeddings to the (ring) memory shard.
+Workload = BASELINE.json configs[1]: "ViT-B/16 encoder, 4k frames (chunk_size=16), fp16; top-10 over 100k x 768".
+Frames are sharded by chunk, memory rows by rank; per-GPU work is fixed as N grows ("weak").
+
+Prints ONE JSON line (rank 0).  `value` = frame embeddings per second over all GPUs, inputs resident in HBM.
+Extra objects: `roofline` (dominant kernel, HIP-event timed inside the timed region), `cpu_baseline` (the oracle
+on the host cores, bounded sample; rank 0, N=1 only), `knn` (the kNN half of the metric on a 1M x 768 index).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MFMA_PEAK_TFLOPS = 2500.0  # dense fp16/bf16, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
+HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--chunks-per-step", type=int, default=16, help="chunks of 16 frames encoded per step per GPU")
+    ap.add_argument("--memory-rows", type=int, default=100_000, help="rows of the memory shard per GPU")
+    ap.add_argument("--topk", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-knn", action="store_true")
+    ap.add_argument("--knn-rows", type=int, default=1_000_000)
+    return ap.parse_args()
+
+
+def cpu_baseline(spec, weights, frames_u8_cpu, mem_cpu_f16, k):
+    """The oracle on the host: same hot path (preprocess + fp32 encoder + reference cosine top-k) on a bounded
+    sample.  Encoder part uses every core torch is given; the cosine port is one thread (as the reference is)."""
+    from oracle import frames_ref, vit_ref, cref
+    n = frames_u8_cpu.shape[0]
+    t0 = time.perf_counter()
+    px = frames_ref.preprocess_ref(frames_u8_cpu, spec["image"], spec["mean"], spec["std"], layout="chw")
+    emb = vit_ref.vit_forward_ref(spec, weights, px, quant=None)
+    t1 = time.perf_counter()
+    q16 = torch.from_numpy(emb).to(torch.float16).numpy()
+    rows_sample = min(mem_cpu_f16.shape[0], 20_000)
+    cref.cosine_topk(q16, mem_cpu_f16[:rows_sample], k, dtype="f16")
+    t2 = time.perf_counter()
+    topk_full = (t2 - t1) * (mem_cpu_f16.shape[0] / rows_sample)  # the scan is linear in rows
+    total = (t1 - t0) + topk_full
+    return {
+        "value": n / total, "unit": "frame-embeddings/s", "cores": int(torch.get_num_threads()), "kind": "port",
+        "sample": f"{n} frames 224x224 through oracle/frames_ref + oracle/vit_ref (fp32, torch CPU, "
+                  f"{torch.get_num_threads()} threads: {t1 - t0:.2f} s) + oracle/cosine_topk_ref.c top-{k} of those "
+                  f"{n} queries over {rows_sample} of {mem_cpu_f16.shape[0]} rows (1 thread, {t2 - t1:.2f} s, scaled "
+                  f"linearly to all rows)",
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import vidmem  # noqa: F401
+    from vidmem import specs, synthetic as syn, _lib
+    from vidmem.encoder import FrameEncoder
+    from vidmem.memory import EmbeddingMemory, topk_merge
+    from vidmem.dist import ShardedRetriever
+
+    spec = specs.VIT_B16_224
+    D, k = spec["hidden"], args.topk
+    F = args.chunks_per_step * 16
+    weights = syn.encoder_weights(spec, seed=42)
+    enc = FrameEncoder(spec, weights, dtype="f16", device=local_rank)
+    ctx = enc.ctx
+
+    # memory shard: R L2-normalised rows (seed 7 + rank), ring so the size stays R while steps append
+    R = args.memory_rows
+    g = torch.Generator(device=dev).manual_seed(7 + rank)
+    mem_rows = torch.randn((R, D), generator=g, device=dev, dtype=torch.float32)
+    mem_rows = (mem_rows / mem_rows.norm(dim=1, keepdim=True)).to(torch.float16)
+    memory = EmbeddingMemory(R, D, "f16", ring=True, device=local_rank)
+    memory.append(mem_rows)
+    retriever = ShardedRetriever(memory, rank, world)
+
+    # synthetic frames resident in HBM: a pool of distinct uint8 frames, cycled through the steps
+    pool_steps = 4
+    gf = torch.Generator(device=dev).manual_seed(1234 + rank)
+    frame_pool = torch.randint(0, 256, (pool_steps, F, 224, 224, 3), generator=gf, device=dev, dtype=torch.uint8)
+
+    def step(i):
+        frames = frame_pool[i % pool_steps]
+        emb = enc.embed_frames(frames)                      # [F, D] fp16, L2-normalised
+        scores, rows = retriever.search(emb, k)             # global top-k for this rank's F queries
+        memory.append(emb)
+        return scores, rows
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+
+    max_events = args.steps * 400 + 64
+    ctx.profile_enable(max_events)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.profile_read()
+    ctx.profile_enable(0)
+    uncert = retriever.uncertified_total()
+
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    frames_total = F * args.steps * world
+    value = frames_total / elapsed
+
+    out = {
+        "metric": "frame-embeddings/sec (+ kNN queries/sec, see knn)", "value": value, "unit": "frame-embeddings/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: ViT-B/16-224 encoder fp16, chunks of 16 frames, cosine top-10 "
+                               f"over a {R}-row x 768 fp16 memory shard per GPU",
+                   "frames_per_step_per_gpu": F, "chunk_size": 16, "memory_rows_per_gpu": R, "top_k": k,
+                   "parallelism": f"dp{world}: frames by chunk, memory by row, RCCL all-gather of queries and "
+                                  "candidates" if world > 1 else "single GPU"},
+        "queries_per_s": value, "uncertified_queries": uncert,
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel (by total time inside the timed region) ------------------------
+        T = enc.tokens
+        H, M = spec["hidden"], spec["mlp"]
+        mbs = []  # micro-batch sizes vm_encode used for F frames (csrc/encoder.hip micro_batch_of)
+        mb = int(os.environ.get("VIDMEM_MICROBATCH", "0")) or 128
+        left = F
+        while left > 0:
+            mbs.append(min(mb, left))
+            left -= mbs[-1]
+        rows = [b * T for b in mbs]
+        flops = {  # algorithmic FLOPs of one step's launches of each GEMM instantiation (2*M*N*K)
+            "gemm_qkv": sum(2.0 * r * 3 * H * H for r in rows) * spec["layers"],
+            "gemm_act": sum(2.0 * r * M * H for r in rows) * spec["layers"],
+            "gemm_resid": sum(2.0 * r * H * H + 2.0 * r * H * M for r in rows) * spec["layers"],
+            "gemm_patch": sum(2.0 * b * (T - 1) * (3 * 16 * 16) * H for b in mbs),
+        }
+        dom = max(flops, key=lambda c: prof[c][0])
+        ms, launches = prof[dom]
+        achieved = flops[dom] * args.steps / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        out["roofline"] = {
+            "bound": "mfma", "kernel": f"gemm_kernel<f16> [{dom}]", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": None,
+            "avg_launch_ms": ms / max(launches, 1), "launches": launches,
+            "flops_per_launch": flops[dom] * args.steps / max(launches, 1),
+        }
+        out["kernel_time_ms_per_step"] = {c: round(v[0] / args.steps, 4) for c, v in prof.items() if v[1]}
+        enc_ms = sum(prof[c][0] for c in ("gemm_patch", "gemm_qkv", "gemm_act", "gemm_resid", "attention",
+                                           "layernorm", "pool")) / args.steps
+        out["encoder_tflops"] = specs.flops_per_frame(spec) * F / (enc_ms * 1e-3) / 1e12 if enc_ms > 0 else None
+
+    # ---- kNN half of the metric: Q=16 queries/launch over a 1M x 768 index (single GPU part of every rank 0) ----
+    if rank == 0 and not args.no_knn:
+        del frame_pool
+        Mk = args.knn_rows
+        big = EmbeddingMemory(Mk, D, "f16", device=local_rank)
+        gk = torch.Generator(device=dev).manual_seed(7)
+        for lo in range(0, Mk, 250_000):
+            n = min(250_000, Mk - lo)
+            x = torch.randn((n, D), generator=gk, device=dev, dtype=torch.float32)
+            big.append((x / x.norm(dim=1, keepdim=True)).to(torch.float16))
+        q = torch.randn((16, D), generator=gk, device=dev, dtype=torch.float32).to(torch.float16)
+        for _ in range(3):
+            big.topk(q, k, check_certified=False)
+        torch.cuda.synchronize()
+        ctx.profile_enable(256)
+        reps = 50
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            big.topk(q, k, check_certified=False)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        p2 = ctx.profile_read()
+        ctx.profile_enable(0)
+        scan_ms = p2["topk_scan"][0] / reps
+        bytes_scan = Mk * D * 2
+        out["knn"] = {
+            "index": f"{Mk} x {D} f16", "Q": 16, "k": k, "queries_per_s": 16 * reps / dt,
+            "ms_per_launch": 1e3 * dt / reps, "scan_kernel_ms": scan_ms,
+            "finalize_kernel_ms": p2["topk_finalize"][0] / reps,
+            "roofline": {"bound": "hbm", "kernel": "topk_scan_kernel", "achieved": bytes_scan / (scan_ms * 1e-3) / 1e9,
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": bytes_scan / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None},
+        }
+        big.close()
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        fr = syn.frames_u8(1234, 4, 224, 224)
+        out["cpu_baseline"] = cpu_baseline(spec, weights, fr, mem_rows[:R].cpu().numpy(), k)
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -156,6 +156,20 @@ int vm_cosine_exact(vm_ctx *ctx, const void *queries, int Q, const void *rows, i
 int vm_topk_merge(vm_ctx *ctx, const double *scores, const int64_t *rows, int parts, int Q, int k,
                   double *out_scores, int64_t *out_rows, void *stream);
 
+/* ---- measurement ---------------------------------------------------------------------------------------
+ * Optional per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg; the
+ * reference's counterpart is MetricsTracker.record_timing, src/core/metrics.py:18-24).  While enabled, every
+ * kernel launch of this context is bracketed by two events from a preallocated pool (no sync, no allocation);
+ * vm_profile_read synchronises the device, folds the pool into per-category totals and clears it.
+ * Not capturable into a hipGraph while enabled. */
+enum vm_prof_cat {
+    VM_PROF_PREPROCESS = 0, VM_PROF_GEMM_PATCH, VM_PROF_GEMM_QKV, VM_PROF_GEMM_ACT, VM_PROF_GEMM_RESID,
+    VM_PROF_ATTENTION, VM_PROF_LAYERNORM, VM_PROF_POOL, VM_PROF_APPEND, VM_PROF_TOPK_SCAN, VM_PROF_TOPK_FINALIZE,
+    VM_PROF_TOPK_EXACT, VM_PROF_TOPK_MERGE, VM_PROF_NCAT
+};
+int vm_profile_enable(vm_ctx *ctx, int max_events);   /* 0 disables and frees the pool */
+int vm_profile_read(vm_ctx *ctx, double *total_ms_host /*[VM_PROF_NCAT]*/, int64_t *launches_host /*[VM_PROF_NCAT]*/);
+
 #ifdef __cplusplus
 }
 #endif

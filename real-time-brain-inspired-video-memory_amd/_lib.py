@@ -28,8 +28,10 @@ SYMBOLS = [
     "vm_memory_create", "vm_memory_destroy", "vm_memory_append", "vm_memory_size", "vm_memory_capacity",
     "vm_memory_dim", "vm_memory_reset", "vm_memory_rows",
     "vm_topk_workspace_bytes", "vm_topk_cosine", "vm_topk_exact_workspace_bytes", "vm_topk_cosine_exact",
-    "vm_cosine_exact", "vm_topk_merge",
+    "vm_cosine_exact", "vm_topk_merge", "vm_profile_enable", "vm_profile_read",
 ]
+PROF_CATS = ["preprocess", "gemm_patch", "gemm_qkv", "gemm_act", "gemm_resid", "attention", "layernorm", "pool",
+             "append", "topk_scan", "topk_finalize", "topk_exact", "topk_merge"]
 
 
 class VidmemError(RuntimeError):
@@ -86,6 +88,8 @@ def lib() -> C.CDLL:
         "vm_topk_cosine_exact": (i32, [vp, vp, i32, i32, i32, f64, i32, i64, i64, vp, vp, vp, sz, vp]),
         "vm_cosine_exact": (i32, [vp, vp, i32, vp, i64, i32, i32, vp, vp]),
         "vm_topk_merge": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp]),
+        "vm_profile_enable": (i32, [vp, i32]),
+        "vm_profile_read": (i32, [vp, C.POINTER(f64), C.POINTER(i64)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError here = header/library drift: fail loudly
@@ -114,6 +118,17 @@ class Context:
         if device not in cls._cache:
             cls._cache[device] = cls(device)
         return cls._cache[device]
+
+    def profile_enable(self, max_events: int) -> None:
+        self.check(self.L.vm_profile_enable(self.handle, int(max_events)))
+
+    def profile_read(self) -> dict:
+        """{category: (total_ms, launches)} since the last read (synchronises the device)."""
+        n = len(PROF_CATS)
+        ms = (C.c_double * n)()
+        cnt = (C.c_int64 * n)()
+        self.check(self.L.vm_profile_read(self.handle, ms, cnt))
+        return {PROF_CATS[i]: (float(ms[i]), int(cnt[i])) for i in range(n)}
 
     def check(self, rc: int) -> None:
         if rc != VM_OK:

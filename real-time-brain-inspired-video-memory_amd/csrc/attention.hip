@@ -1,0 +1,167 @@
+// Self-attention of the vision encoder, one workgroup per (frame, head), head dim 64, full-row softmax.
+//
+// Sequence lengths here are 197 (ViT-B/16) and 577 (CLIP-L/14-336): a whole score row fits in registers, so there
+// is no online rescaling.  Per wave, 16 query rows at a time:
+//   S^T = K . Q^T     MFMA 16x16x32 with K (from LDS) as the A operand and Q (registers) as B: the lane that owns
+//                     query column (lane & 15) holds that query's scores for keys 16*kt + 4*(lane>>4) + j, so the
+//                     row max / row sum are register reductions plus two shuffles (xor 16, 32).
+//   P  = exp2(..)     fp32, masked keys -> 0, packed to 16-bit in exactly the B-operand order of the next MFMA
+//                     (k slot j<4 -> key 32ks+4h+j, j>=4 -> key 32ks+16+4h+j-4): no lane movement, no LDS.
+//   O^T = V^T . P^T   V^T[d][key] staged in LDS gives the A fragments with two ds_read_b64; the lane ends up with 4
+//                     consecutive d of one query -> 8-byte stores of the context row.
+// LDS: K tile [keys][64] with chunk ^= (key & 7) swizzle (conflict-free ds_read_b128); V^T rows padded to
+// 32*NS + 8 elements (row stride = 208 mod 256 bytes: conflict-free ds_read_b64).
+#include "vm_internal.h"
+#include "vm_kernels.h"
+
+namespace {
+
+template <int DT, int NT>  // NT = key tiles of 16 (13 for 197 tokens, 37 for 577)
+__global__ void __launch_bounds__(256) attention_kernel(const uint16_t *__restrict__ qkv,
+                                                        uint16_t *__restrict__ ctx_out, int T, int heads) {
+    using E = vm_elem<DT>;
+    using vec8 = typename E::vec8;
+    constexpr int NS = (NT + 1) / 2;     // 32-key steps of the PV product
+    constexpr int VT_STRIDE = NS * 32 + 8;  // elements per V^T row
+    constexpr int KROWS = NT * 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *kl = smem;                                                          // [KROWS][128 B]
+    uint16_t *vt = reinterpret_cast<uint16_t *>(smem + (size_t)KROWS * 128);  // [64][VT_STRIDE]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, h = lane >> 4;
+    const int b = blockIdx.x / heads, head = blockIdx.x - b * heads;
+    const int H = heads * 64;
+    const size_t ld = (size_t)3 * H;
+    const uint16_t *base = qkv + (size_t)b * T * ld + head * 64;
+
+    // ---- stage K (swizzled rows) and V^T ----------------------------------------------------------------
+    for (int idx = tid; idx < KROWS * 8; idx += 256) {
+        const int key = idx >> 3, c = idx & 7;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (key < T) v = *reinterpret_cast<const uint4 *>(base + (size_t)key * ld + H + c * 8);
+        *reinterpret_cast<uint4 *>(kl + key * 128 + ((c ^ (key & 7)) << 4)) = v;
+    }
+    for (int idx = tid; idx < NS * 32 * 8; idx += 256) {
+        const int key = idx >> 3, c = idx & 7;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (key < T) v = *reinterpret_cast<const uint4 *>(base + (size_t)key * ld + 2 * H + c * 8);
+        const uint16_t *e = reinterpret_cast<const uint16_t *>(&v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) vt[(c * 8 + i) * VT_STRIDE + key] = e[i];
+    }
+    __syncthreads();
+
+    const float scale_log2e = 0.125f * 1.44269504088896340736f;  // 1/sqrt(64) * log2(e)
+
+    for (int qt = wave; qt < NT; qt += 4) {
+        int qtok = qt * 16 + r16;
+        const bool qvalid = qtok < T;
+        if (!qvalid) qtok = T - 1;
+        const uint16_t *qp = base + (size_t)qtok * ld;
+        const vec8 q0 = __builtin_bit_cast(vec8, *reinterpret_cast<const uint4 *>(qp + 8 * h));
+        const vec8 q1 = __builtin_bit_cast(vec8, *reinterpret_cast<const uint4 *>(qp + 32 + 8 * h));
+
+        f32x4 s[NT];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            const int key = kt * 16 + r16;
+            const vec8 k0 = *reinterpret_cast<const vec8 *>(kl + key * 128 + ((h ^ (key & 7)) << 4));
+            const vec8 k1 = *reinterpret_cast<const vec8 *>(kl + key * 128 + (((h + 4) ^ (key & 7)) << 4));
+            f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+            a = E::mfma16(k0, q0, a);
+            a = E::mfma16(k1, q1, a);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool kvalid = kt * 16 + 4 * h + j < T;
+                a[j] = kvalid ? a[j] * scale_log2e : -INFINITY;
+                mx = fmaxf(mx, a[j]);
+            }
+            s[kt] = a;
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float e = exp2f(s[kt][j] - mx);
+                s[kt][j] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NS; ++ks) {
+            uint16_t pe[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                pe[j] = E::from_float(s[2 * ks][j]);
+                pe[4 + j] = (2 * ks + 1 < NT) ? E::from_float(s[2 * ks + 1][j]) : (uint16_t)0;
+            }
+            vec8 pf;
+            __builtin_memcpy(&pf, pe, 16);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const uint16_t *vrow = vt + (dt * 16 + r16) * VT_STRIDE + ks * 32 + 4 * h;
+                uint2 lo = *reinterpret_cast<const uint2 *>(vrow);
+                uint2 hi = *reinterpret_cast<const uint2 *>(vrow + 16);
+                uint4 both = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                o[dt] = E::mfma16(__builtin_bit_cast(vec8, both), pf, o[dt]);
+            }
+        }
+        if (qvalid) {
+            uint16_t *dst = ctx_out + ((size_t)b * T + qtok) * H + head * 64 + 4 * h;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                uint16_t oe[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) oe[j] = E::from_float(o[dt][j] * inv);
+                uint2 pk;
+                __builtin_memcpy(&pk, oe, 8);
+                *reinterpret_cast<uint2 *>(dst + dt * 16) = pk;
+            }
+        }
+    }
+}
+
+template <int DT, int NT>
+int launch(vm_ctx *ctx, const uint16_t *qkv, uint16_t *out, int B, int T, int heads, hipStream_t st) {
+    constexpr int NS = (NT + 1) / 2;
+    const size_t lds = (size_t)NT * 16 * 128 + (size_t)64 * (NS * 32 + 8) * 2;
+    auto kern = attention_kernel<DT, NT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        VM_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    vm_prof_scope prof(ctx, VM_PROF_ATTENTION, st);
+    kern<<<B * heads, 256, lds, st>>>(qkv, out, T, heads);
+    VM_LAUNCH_CHECK(ctx);
+    return VM_OK;
+}
+
+template <int DT>
+int dispatch(vm_ctx *ctx, const uint16_t *qkv, uint16_t *out, int B, int T, int heads, hipStream_t st) {
+    const int nt = (T + 15) / 16;
+    if (nt <= 2) return launch<DT, 2>(ctx, qkv, out, B, T, heads, st);
+    if (nt <= 5) return launch<DT, 5>(ctx, qkv, out, B, T, heads, st);
+    if (nt <= 13) return launch<DT, 13>(ctx, qkv, out, B, T, heads, st);
+    if (nt <= 37) return launch<DT, 37>(ctx, qkv, out, B, T, heads, st);
+    return vm_fail(ctx, VM_ERR_UNSUPPORTED, "attention: %d tokens > 592", T);
+}
+
+}  // namespace
+
+int vm_attention(vm_ctx *ctx, int dtype, const uint16_t *qkv, uint16_t *ctx_out, int B, int T, int heads,
+                 hipStream_t st) {
+    return dtype == VM_F16 ? dispatch<VM_F16>(ctx, qkv, ctx_out, B, T, heads, st)
+                           : dispatch<VM_BF16>(ctx, qkv, ctx_out, B, T, heads, st);
+}

@@ -26,6 +26,7 @@ extern "C" int vm_init(int device, vm_ctx **out) {
     }
     if (hipSetDevice(device) != hipSuccess) return VM_ERR_HIP;
     vm_ctx *ctx = new vm_ctx();
+    memset(ctx, 0, sizeof(*ctx));
     ctx->device = device;
     ctx->num_cus = prop.multiProcessorCount;
     ctx->err[0] = 0;
@@ -33,7 +34,53 @@ extern "C" int vm_init(int device, vm_ctx **out) {
     return VM_OK;
 }
 
-extern "C" void vm_destroy(vm_ctx *ctx) { delete ctx; }
+extern "C" void vm_destroy(vm_ctx *ctx) {
+    if (!ctx) return;
+    vm_profile_enable(ctx, 0);
+    delete ctx;
+}
+
+extern "C" int vm_profile_enable(vm_ctx *ctx, int max_events) {
+    if (!ctx) return VM_ERR_INVALID;
+    if (ctx->prof_ev) {
+        for (int i = 0; i < 2 * ctx->prof_cap; ++i) (void)hipEventDestroy(ctx->prof_ev[i]);
+        delete[] ctx->prof_ev;
+        delete[] ctx->prof_cat;
+        ctx->prof_ev = nullptr;
+        ctx->prof_cat = nullptr;
+    }
+    ctx->prof_cap = ctx->prof_n = 0;
+    for (int i = 0; i < VM_PROF_NCAT; ++i) {
+        ctx->prof_ms[i] = 0.0;
+        ctx->prof_launches[i] = 0;
+    }
+    if (max_events <= 0) return VM_OK;
+    ctx->prof_ev = new hipEvent_t[2 * (size_t)max_events];
+    ctx->prof_cat = new int[max_events];
+    for (int i = 0; i < 2 * max_events; ++i) VM_HIP(ctx, hipEventCreate(&ctx->prof_ev[i]));
+    ctx->prof_cap = max_events;
+    return VM_OK;
+}
+
+extern "C" int vm_profile_read(vm_ctx *ctx, double *total_ms, int64_t *launches) {
+    if (!ctx || !total_ms || !launches) return VM_ERR_INVALID;
+    VM_HIP(ctx, hipDeviceSynchronize());
+    for (int i = 0; i < ctx->prof_n; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ctx->prof_ev[2 * i], ctx->prof_ev[2 * i + 1]) == hipSuccess) {
+            ctx->prof_ms[ctx->prof_cat[i]] += ms;
+            ctx->prof_launches[ctx->prof_cat[i]] += 1;
+        }
+    }
+    ctx->prof_n = 0;
+    for (int i = 0; i < VM_PROF_NCAT; ++i) {
+        total_ms[i] = ctx->prof_ms[i];
+        launches[i] = ctx->prof_launches[i];
+        ctx->prof_ms[i] = 0.0;
+        ctx->prof_launches[i] = 0;
+    }
+    return VM_OK;
+}
 
 extern "C" const char *vm_last_error(vm_ctx *ctx) { return ctx ? ctx->err : g_init_err; }
 
@@ -163,6 +210,7 @@ extern "C" int vm_preprocess(vm_ctx *ctx, const uint8_t *frames, int B, int H, i
     const int64_t cap = (int64_t)ctx->num_cus * 16;
     if (blocks > cap) blocks = cap;
     hipStream_t st = (hipStream_t)stream;
+    vm_prof_scope prof(ctx, VM_PROF_PREPROCESS, st);
     if (dtype == VM_F16)
         preprocess_kernel<VM_F16><<<(unsigned)blocks, 256, 0, st>>>(p);
     else

@@ -1,12 +1,433 @@
-// placeholder until the encoder lands (next commit)
+// Vision encoder forward (ViT-B/16-224, CLIP-ViT-L/14-336 and anything of the same family):
+// patch rows -> patch-embed GEMM (+bias +pos) -> [pre-LN] -> L x {LN1 -> QKV GEMM -> attention -> proj GEMM (+resid)
+// -> LN2 -> FC1 GEMM (+act) -> FC2 GEMM (+resid)} -> final LN of the CLS row -> [projection] -> [L2 norm] -> 16 bit.
+//
+// This is the work the reference leaves to a remote model server: VLMExtractor._call_vlm_api
+// (src/pipeline/vlm_extractor.py:130-185) and OpenAIEmbeddings.aembed_query (src/components/neo4j_handler.py:27-31,
+// src/components/pre_llm_injector.py:207-221).  Residual stream fp32; every GEMM operand 16 bit; accumulation fp32.
 #include "vm_internal.h"
-struct vm_encoder { vm_ctx *ctx; };
-extern "C" int vm_encoder_create(vm_ctx *ctx, const vm_encoder_desc *, const void *const *, int, vm_encoder **) {
-    return vm_fail(ctx, VM_ERR_UNSUPPORTED, "encoder not built yet");
+#include "vm_kernels.h"
+
+// ---------------------------------------------------------------------------------------------------------
+// small HBM-bound kernels
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
 }
-extern "C" void vm_encoder_destroy(vm_encoder *) {}
-extern "C" int vm_encoder_tokens(const vm_encoder *) { return 0; }
-extern "C" int vm_encoder_patch_k(const vm_encoder *) { return 0; }
-extern "C" int vm_encoder_out_dim(const vm_encoder *) { return 0; }
-extern "C" size_t vm_encode_workspace_bytes(const vm_encoder *, int) { return 0; }
-extern "C" int vm_encode(vm_encoder *, const void *, int, void *, int, void *, size_t, void *) { return VM_ERR_UNSUPPORTED; }
+
+// One wave per row, H = 256 * VPL elements, lane owns float4 chunks lane + 64*i.  Two-pass statistics in
+// registers (mean, then mean of squared deviations), as the oracle computes them.
+template <int DT, int VPL, bool TO16>
+__global__ void __launch_bounds__(256) layernorm_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                        const float *__restrict__ beta, float eps,
+                                                        uint16_t *__restrict__ out16, float *__restrict__ out32,
+                                                        int rows, int H, int64_t row_stride) {
+    using E = vm_elem<DT>;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float4 *xr = reinterpret_cast<const float4 *>(x + (size_t)row * row_stride);
+    float4 v[VPL];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        v[i] = xr[lane + 64 * i];
+        sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(sum) / (float)H;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+        sq += (a * a + b * b) + (c * c + d * d);
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)H + eps);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const float4 g4 = reinterpret_cast<const float4 *>(gamma)[lane + 64 * i];
+        const float4 b4 = reinterpret_cast<const float4 *>(beta)[lane + 64 * i];
+        const float y0 = (v[i].x - mean) * rstd * g4.x + b4.x, y1 = (v[i].y - mean) * rstd * g4.y + b4.y;
+        const float y2 = (v[i].z - mean) * rstd * g4.z + b4.z, y3 = (v[i].w - mean) * rstd * g4.w + b4.w;
+        if (TO16) {
+            uint16_t o[4] = {E::from_float(y0), E::from_float(y1), E::from_float(y2), E::from_float(y3)};
+            uint2 pk;
+            __builtin_memcpy(&pk, o, 8);
+            reinterpret_cast<uint2 *>(out16 + (size_t)row * H)[lane + 64 * i] = pk;
+        } else {
+            reinterpret_cast<float4 *>(out32 + (size_t)row * row_stride)[lane + 64 * i] = make_float4(y0, y1, y2, y3);
+        }
+    }
+}
+
+__global__ void cls_rows_kernel(float *__restrict__ x, const float *__restrict__ cls, const float *__restrict__ pos,
+                                int T, int H) {
+    float *dst = x + (size_t)blockIdx.x * T * H;
+    for (int i = threadIdx.x; i < H; i += blockDim.x) dst[i] = cls[i] + pos[i];
+}
+
+// One block per frame: LayerNorm of the CLS row (fp32), optional projection W[proj_dim, H] (16-bit weights,
+// 16-bit rounded input, fp32 accumulate), optional L2 normalisation, cast to 16 bit.
+template <int DT>
+__global__ void __launch_bounds__(256) pool_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                   const float *__restrict__ beta, float eps,
+                                                   const uint16_t *__restrict__ proj_w, int proj_dim, int l2,
+                                                   uint16_t *__restrict__ out, int T, int H) {
+    using E = vm_elem<DT>;
+    extern __shared__ __attribute__((aligned(16))) float sh[];  // [H] normalised row, then [out_dim] result
+    __shared__ float red[8];
+    float *y = sh;
+    float *res = sh + H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *row = x + (size_t)blockIdx.x * T * H;
+    auto block_sum = [&](float v) {
+        v = wave_sum(v);
+        __syncthreads();
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        return (red[0] + red[1]) + (red[2] + red[3]);
+    };
+    float s = 0.f;
+    for (int i = tid; i < H; i += 256) s += row[i];
+    const float mean = block_sum(s) / (float)H;
+    float sq = 0.f;
+    for (int i = tid; i < H; i += 256) {
+        const float d = row[i] - mean;
+        sq += d * d;
+    }
+    const float rstd = rsqrtf(block_sum(sq) / (float)H + eps);
+    for (int i = tid; i < H; i += 256) y[i] = (row[i] - mean) * rstd * gamma[i] + beta[i];
+    __syncthreads();
+    int od = H;
+    const float *src = y;
+    if (proj_dim > 0) {
+        od = proj_dim;
+        for (int o = wave; o < proj_dim; o += 4) {  // one wave per output row
+            const uint16_t *w = proj_w + (size_t)o * H;
+            float acc = 0.f;
+            for (int i = lane; i < H; i += 64) acc += E::to_float(E::from_float(y[i])) * E::to_float(w[i]);
+            acc = wave_sum(acc);
+            if (lane == 0) res[o] = acc;
+        }
+        __syncthreads();
+        src = res;
+    }
+    float nn = 0.f;
+    for (int i = tid; i < od; i += 256) nn += src[i] * src[i];
+    float inv = 1.f;
+    if (l2) {
+        const float nrm = sqrtf(block_sum(nn));
+        inv = 1.f / fmaxf(nrm, 1e-12f);
+    }
+    for (int i = tid; i < od; i += 256) out[(size_t)blockIdx.x * od + i] = E::from_float(src[i] * inv);
+}
+
+}  // namespace
+
+int vm_layernorm16(vm_ctx *ctx, int dtype, const float *x, const float *gamma, const float *beta, float eps,
+                   uint16_t *out, int rows, int H, hipStream_t st) {
+    const int blocks = (rows + 3) / 4;
+    vm_prof_scope prof(ctx, VM_PROF_LAYERNORM, st);
+#define LN(DTV, VPLV) layernorm_kernel<DTV, VPLV, true><<<blocks, 256, 0, st>>>(x, gamma, beta, eps, out, nullptr, rows, H, H)
+    if (H % 256 != 0 || H / 256 > 8) return vm_fail(ctx, VM_ERR_UNSUPPORTED, "layernorm width %d", H);
+    const int vpl = H / 256;
+    if (dtype == VM_F16) {
+        switch (vpl) {
+            case 1: LN(VM_F16, 1); break;
+            case 2: LN(VM_F16, 2); break;
+            case 3: LN(VM_F16, 3); break;
+            case 4: LN(VM_F16, 4); break;
+            default: return vm_fail(ctx, VM_ERR_UNSUPPORTED, "layernorm width %d", H);
+        }
+    } else {
+        switch (vpl) {
+            case 1: LN(VM_BF16, 1); break;
+            case 2: LN(VM_BF16, 2); break;
+            case 3: LN(VM_BF16, 3); break;
+            case 4: LN(VM_BF16, 4); break;
+            default: return vm_fail(ctx, VM_ERR_UNSUPPORTED, "layernorm width %d", H);
+        }
+    }
+#undef LN
+    VM_LAUNCH_CHECK(ctx);
+    return VM_OK;
+}
+
+int vm_layernorm32_inplace(vm_ctx *ctx, float *x, const float *gamma, const float *beta, float eps, int rows, int H,
+                           hipStream_t st) {
+    const int blocks = (rows + 3) / 4;
+    vm_prof_scope prof(ctx, VM_PROF_LAYERNORM, st);
+#define LN(VPLV) layernorm_kernel<VM_F16, VPLV, false><<<blocks, 256, 0, st>>>(x, gamma, beta, eps, nullptr, x, rows, H, H)
+    switch (H / 256) {
+        case 1: LN(1); break;
+        case 2: LN(2); break;
+        case 3: LN(3); break;
+        case 4: LN(4); break;
+        default: return vm_fail(ctx, VM_ERR_UNSUPPORTED, "layernorm width %d", H);
+    }
+#undef LN
+    VM_LAUNCH_CHECK(ctx);
+    return VM_OK;
+}
+
+int vm_cls_rows(vm_ctx *ctx, float *x, const float *cls, const float *pos, int B, int T, int H, hipStream_t st) {
+    vm_prof_scope prof(ctx, VM_PROF_POOL, st);
+    cls_rows_kernel<<<B, 256, 0, st>>>(x, cls, pos, T, H);
+    VM_LAUNCH_CHECK(ctx);
+    return VM_OK;
+}
+
+int vm_pool(vm_ctx *ctx, int dtype, const float *x, const float *gamma, const float *beta, float eps,
+            const uint16_t *proj_w, int proj_dim, int l2, uint16_t *out, int B, int T, int H, hipStream_t st) {
+    const size_t lds = (size_t)(H + (proj_dim > 0 ? proj_dim : 0)) * 4;
+    vm_prof_scope prof(ctx, VM_PROF_POOL, st);
+    if (dtype == VM_F16)
+        pool_kernel<VM_F16><<<B, 256, lds, st>>>(x, gamma, beta, eps, proj_w, proj_dim, l2, out, T, H);
+    else
+        pool_kernel<VM_BF16><<<B, 256, lds, st>>>(x, gamma, beta, eps, proj_w, proj_dim, l2, out, T, H);
+    VM_LAUNCH_CHECK(ctx);
+    return VM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// handle + orchestration
+// ---------------------------------------------------------------------------------------------------------
+struct LayerW {
+    float *ln1_g, *ln1_b, *qkv_b, *proj_b, *ln2_g, *ln2_b, *fc1_b, *fc2_b;
+    uint16_t *qkv_w, *proj_w, *fc1_w, *fc2_w;
+};
+struct vm_encoder {
+    vm_ctx *ctx;
+    vm_encoder_desc d;
+    int tokens, patches, patch_k, out_dim;
+    char *blob;  // one device allocation holding every weight
+    uint16_t *patch_w, *proj_w;
+    float *patch_b, *cls, *pos, *pre_g, *pre_b, *ln_g, *ln_b;
+    LayerW *layers;
+    int micro_batch;
+};
+
+static int round_up(int x, int a) { return (x + a - 1) / a * a; }
+
+extern "C" int vm_encoder_create(vm_ctx *ctx, const vm_encoder_desc *desc, const void *const *wp, int n_weights,
+                                 vm_encoder **out) {
+    if (!ctx || !desc || !wp || !out) return VM_ERR_INVALID;
+    const vm_encoder_desc &d = *desc;
+    if (d.hidden % 256 != 0 || d.hidden > 1024 || d.heads * 64 != d.hidden)
+        return vm_fail(ctx, VM_ERR_UNSUPPORTED, "hidden=%d heads=%d: need hidden %% 256 == 0, <= 1024, head dim 64",
+                       d.hidden, d.heads);
+    if (d.mlp % 128 != 0 || d.image % d.patch != 0 || d.layers <= 0 || d.image % 8 != 0)
+        return vm_fail(ctx, VM_ERR_UNSUPPORTED, "bad mlp/image/patch/layers");
+    if (d.dtype != VM_F16 && d.dtype != VM_BF16) return vm_fail(ctx, VM_ERR_INVALID, "bad dtype");
+    if (d.proj_dim < 0 || d.proj_dim % 8 != 0) return vm_fail(ctx, VM_ERR_UNSUPPORTED, "proj_dim %d", d.proj_dim);
+    if (n_weights != 9 + 12 * d.layers)
+        return vm_fail(ctx, VM_ERR_INVALID, "expected %d weight pointers, got %d", 9 + 12 * d.layers, n_weights);
+    VM_HIP(ctx, hipSetDevice(ctx->device));
+    vm_encoder *e = new vm_encoder();
+    memset(e, 0, sizeof(*e));
+    e->ctx = ctx;
+    e->d = d;
+    const int g = d.image / d.patch;
+    e->patches = g * g;
+    e->tokens = e->patches + 1;
+    e->patch_k = round_up(3 * d.patch * d.patch, 64);
+    e->out_dim = d.proj_dim ? d.proj_dim : d.hidden;
+    if (e->tokens > 592) {
+        delete e;
+        return vm_fail(ctx, VM_ERR_UNSUPPORTED, "%d tokens per frame > 592", e->tokens);
+    }
+    const char *mb = getenv("VIDMEM_MICROBATCH");
+    e->micro_batch = mb ? atoi(mb) : 0;
+    const size_t H = d.hidden, M = d.mlp;
+    // byte sizes in header order
+    auto a256 = [](size_t b) { return vm_align_up(b, 256); };
+    size_t total = 0;
+    auto take = [&](size_t bytes) {
+        size_t off = total;
+        total += a256(bytes);
+        return off;
+    };
+    const size_t o_patch_w = take(H * e->patch_k * 2), o_patch_b = take(H * 4), o_cls = take(H * 4),
+                 o_pos = take((size_t)e->tokens * H * 4), o_pre_g = take(H * 4), o_pre_b = take(H * 4),
+                 o_ln_g = take(H * 4), o_ln_b = take(H * 4), o_proj = take((size_t)(d.proj_dim ? d.proj_dim : 0) * H * 2);
+    struct LO {
+        size_t o[12];
+    };
+    LO *lo = new LO[d.layers];
+    const size_t lsz[12] = {H * 4, H * 4, 3 * H * H * 2, 3 * H * 4, H * H * 2, H * 4,
+                            H * 4, H * 4, M * H * 2,     M * 4,     H * M * 2, H * 4};
+    for (int l = 0; l < d.layers; ++l)
+        for (int i = 0; i < 12; ++i) lo[l].o[i] = take(lsz[i]);
+    hipError_t er = hipMalloc((void **)&e->blob, total);
+    if (er != hipSuccess) {
+        delete[] lo;
+        delete e;
+        return vm_fail(ctx, VM_ERR_NOMEM, "encoder weights: hipMalloc(%zu) failed", total);
+    }
+    auto copy = [&](size_t off, const void *src, size_t bytes) -> hipError_t {
+        if (bytes == 0) return hipSuccess;
+        if (!src) return hipErrorInvalidValue;
+        return hipMemcpy(e->blob + off, src, bytes, hipMemcpyDeviceToDevice);
+    };
+    er = copy(o_patch_w, wp[0], H * e->patch_k * 2);
+    if (er == hipSuccess) er = d.patch_bias ? copy(o_patch_b, wp[1], H * 4) : hipMemset(e->blob + o_patch_b, 0, H * 4);
+    if (er == hipSuccess) er = copy(o_cls, wp[2], H * 4);
+    if (er == hipSuccess) er = copy(o_pos, wp[3], (size_t)e->tokens * H * 4);
+    if (er == hipSuccess && d.pre_ln) er = copy(o_pre_g, wp[4], H * 4);
+    if (er == hipSuccess && d.pre_ln) er = copy(o_pre_b, wp[5], H * 4);
+    if (er == hipSuccess) er = copy(o_ln_g, wp[6], H * 4);
+    if (er == hipSuccess) er = copy(o_ln_b, wp[7], H * 4);
+    if (er == hipSuccess && d.proj_dim) er = copy(o_proj, wp[8], (size_t)d.proj_dim * H * 2);
+    e->layers = new LayerW[d.layers];
+    for (int l = 0; l < d.layers && er == hipSuccess; ++l) {
+        for (int i = 0; i < 12 && er == hipSuccess; ++i) er = copy(lo[l].o[i], wp[9 + 12 * l + i], lsz[i]);
+        LayerW &w = e->layers[l];
+        char *b = e->blob;
+        w.ln1_g = (float *)(b + lo[l].o[0]);
+        w.ln1_b = (float *)(b + lo[l].o[1]);
+        w.qkv_w = (uint16_t *)(b + lo[l].o[2]);
+        w.qkv_b = (float *)(b + lo[l].o[3]);
+        w.proj_w = (uint16_t *)(b + lo[l].o[4]);
+        w.proj_b = (float *)(b + lo[l].o[5]);
+        w.ln2_g = (float *)(b + lo[l].o[6]);
+        w.ln2_b = (float *)(b + lo[l].o[7]);
+        w.fc1_w = (uint16_t *)(b + lo[l].o[8]);
+        w.fc1_b = (float *)(b + lo[l].o[9]);
+        w.fc2_w = (uint16_t *)(b + lo[l].o[10]);
+        w.fc2_b = (float *)(b + lo[l].o[11]);
+    }
+    delete[] lo;
+    if (er != hipSuccess) {
+        vm_encoder_destroy(e);
+        return vm_fail(ctx, VM_ERR_HIP, "encoder weight copy failed: %s (null or short weight pointer?)",
+                       hipGetErrorString(er));
+    }
+    char *b = e->blob;
+    e->patch_w = (uint16_t *)(b + o_patch_w);
+    e->patch_b = (float *)(b + o_patch_b);
+    e->cls = (float *)(b + o_cls);
+    e->pos = (float *)(b + o_pos);
+    e->pre_g = (float *)(b + o_pre_g);
+    e->pre_b = (float *)(b + o_pre_b);
+    e->ln_g = (float *)(b + o_ln_g);
+    e->ln_b = (float *)(b + o_ln_b);
+    e->proj_w = d.proj_dim ? (uint16_t *)(b + o_proj) : nullptr;
+    *out = e;
+    return VM_OK;
+}
+
+extern "C" void vm_encoder_destroy(vm_encoder *e) {
+    if (!e) return;
+    if (e->blob) (void)hipFree(e->blob);
+    delete[] e->layers;
+    delete e;
+}
+
+extern "C" int vm_encoder_tokens(const vm_encoder *e) { return e ? e->tokens : 0; }
+extern "C" int vm_encoder_patch_k(const vm_encoder *e) { return e ? e->patch_k : 0; }
+extern "C" int vm_encoder_out_dim(const vm_encoder *e) { return e ? e->out_dim : 0; }
+
+static int micro_batch_of(const vm_encoder *e, int B) {
+    // Frames per pass.  Large enough to fill 256 CUs with 128x128 GEMM tiles, small enough that one pass's
+    // activations (~1.3 MB/frame for ViT-B/16) stay inside the 256 MiB Infinity Cache between kernels.
+    int mb = e->micro_batch > 0 ? e->micro_batch : (e->d.hidden <= 768 ? 128 : 32);
+    return B < mb ? B : mb;
+}
+
+struct Ws {
+    float *x32;
+    uint16_t *a16, *qkv16, *mlp16;
+    size_t bytes;
+};
+static Ws carve(const vm_encoder *e, int mb, void *base) {
+    const size_t rows = (size_t)mb * e->tokens, H = e->d.hidden, M = e->d.mlp;
+    Ws w;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off += vm_align_up(bytes, 256);
+        return (char *)base + o;
+    };
+    w.x32 = (float *)take(rows * H * 4);
+    w.a16 = (uint16_t *)take(rows * H * 2);
+    w.qkv16 = (uint16_t *)take(rows * 3 * H * 2);
+    w.mlp16 = (uint16_t *)take(rows * M * 2);
+    w.bytes = off;
+    return w;
+}
+
+extern "C" size_t vm_encode_workspace_bytes(const vm_encoder *e, int B) {
+    if (!e || B <= 0) return 0;
+    return carve(e, micro_batch_of(e, B), nullptr).bytes;
+}
+
+extern "C" int vm_encode(vm_encoder *e, const void *patches, int B, void *out_emb, int l2_normalise,
+                         void *workspace, size_t workspace_bytes, void *stream) {
+    if (!e) return VM_ERR_INVALID;
+    vm_ctx *ctx = e->ctx;
+    if (!patches || !out_emb || B <= 0) return vm_fail(ctx, VM_ERR_INVALID, "vm_encode: bad arguments");
+    const int mb = micro_batch_of(e, B);
+    const Ws ws = carve(e, mb, workspace);
+    if (!workspace || workspace_bytes < ws.bytes)
+        return vm_fail(ctx, VM_ERR_NOMEM, "vm_encode: workspace %zu < %zu", workspace_bytes, ws.bytes);
+    if (((uintptr_t)workspace & 255) || ((uintptr_t)patches & 15) || ((uintptr_t)out_emb & 15))
+        return vm_fail(ctx, VM_ERR_INVALID, "vm_encode: workspace must be 256-byte, tensors 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const vm_encoder_desc &d = e->d;
+    const int H = d.hidden, T = e->tokens, P = e->patches, dt = d.dtype;
+    const int act_epi = d.act == VM_ACT_QUICK_GELU ? EPI_QGELU16 : EPI_GELU16;
+    int rc;
+    for (int b0 = 0; b0 < B; b0 += mb) {
+        const int nb = B - b0 < mb ? B - b0 : mb;
+        const int rows = nb * T;
+        GemmArgs g;
+        memset(&g, 0, sizeof(g));
+        // patch embedding: [nb*P, patch_k] x [H, patch_k]^T -> x32 rows 1.. of every frame (+bias +pos)
+        g.X = (const uint16_t *)patches + (size_t)b0 * P * e->patch_k;
+        g.W = e->patch_w;
+        g.bias = e->patch_b;
+        g.out32 = ws.x32;
+        g.pos = e->pos;
+        g.M = nb * P;
+        g.N = H;
+        g.K = e->patch_k;
+        g.ldx = e->patch_k;
+        g.ldo = H;
+        g.P = P;
+        g.T = T;
+        if ((rc = vm_gemm(ctx, dt, g, EPI_PATCH, st)) != VM_OK) return rc;
+        if ((rc = vm_cls_rows(ctx, ws.x32, e->cls, e->pos, nb, T, H, st)) != VM_OK) return rc;
+        if (d.pre_ln && (rc = vm_layernorm32_inplace(ctx, ws.x32, e->pre_g, e->pre_b, d.ln_eps, rows, H, st)) != VM_OK)
+            return rc;
+        for (int l = 0; l < d.layers; ++l) {
+            const LayerW &w = e->layers[l];
+            if ((rc = vm_layernorm16(ctx, dt, ws.x32, w.ln1_g, w.ln1_b, d.ln_eps, ws.a16, rows, H, st)) != VM_OK) return rc;
+            memset(&g, 0, sizeof(g));
+            g.X = ws.a16; g.W = w.qkv_w; g.bias = w.qkv_b; g.out16 = ws.qkv16;
+            g.M = rows; g.N = 3 * H; g.K = H; g.ldx = H; g.ldo = 3 * H;
+            if ((rc = vm_gemm(ctx, dt, g, EPI_STORE16, st)) != VM_OK) return rc;
+            if ((rc = vm_attention(ctx, dt, ws.qkv16, ws.a16, nb, T, d.heads, st)) != VM_OK) return rc;
+            memset(&g, 0, sizeof(g));
+            g.X = ws.a16; g.W = w.proj_w; g.bias = w.proj_b; g.out32 = ws.x32;
+            g.M = rows; g.N = H; g.K = H; g.ldx = H; g.ldo = H;
+            if ((rc = vm_gemm(ctx, dt, g, EPI_RESID32, st)) != VM_OK) return rc;
+            if ((rc = vm_layernorm16(ctx, dt, ws.x32, w.ln2_g, w.ln2_b, d.ln_eps, ws.a16, rows, H, st)) != VM_OK) return rc;
+            memset(&g, 0, sizeof(g));
+            g.X = ws.a16; g.W = w.fc1_w; g.bias = w.fc1_b; g.out16 = ws.mlp16;
+            g.M = rows; g.N = d.mlp; g.K = H; g.ldx = H; g.ldo = d.mlp;
+            if ((rc = vm_gemm(ctx, dt, g, act_epi, st)) != VM_OK) return rc;
+            memset(&g, 0, sizeof(g));
+            g.X = ws.mlp16; g.W = w.fc2_w; g.bias = w.fc2_b; g.out32 = ws.x32;
+            g.M = rows; g.N = H; g.K = d.mlp; g.ldx = d.mlp; g.ldo = H;
+            if ((rc = vm_gemm(ctx, dt, g, EPI_RESID32, st)) != VM_OK) return rc;
+        }
+        uint16_t *dst = (uint16_t *)out_emb + (size_t)b0 * e->out_dim;
+        if ((rc = vm_pool(ctx, dt, ws.x32, e->ln_g, e->ln_b, d.ln_eps, e->proj_w, d.proj_dim, l2_normalise, dst, nb, T,
+                          H, st)) != VM_OK)
+            return rc;
+    }
+    return VM_OK;
+}

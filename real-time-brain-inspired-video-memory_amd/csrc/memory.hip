@@ -97,6 +97,7 @@ extern "C" int vm_memory_append(vm_memory *m, const void *rows, int B, int64_t *
                        (long long)m->cap);
     if (m->ring && B > m->cap) return vm_fail(ctx, VM_ERR_INVALID, "append of %d rows exceeds ring capacity", B);
     hipStream_t st = (hipStream_t)stream;
+    vm_prof_scope prof(ctx, VM_PROF_APPEND, st);
     if (m->dtype == VM_F16)
         memory_append_kernel<VM_F16><<<B, 128, 0, st>>>((const uint16_t *)rows, B, m->D, m->rows, m->norm64,
                                                        m->rnorm32, m->d_total, m->cap, m->ring);

@@ -454,6 +454,7 @@ int launch_scan(vm_memory *m, const ScanPlan &p, const void *queries, int Q, flo
         if (e != hipSuccess) return vm_fail(m->ctx, VM_ERR_HIP, "LDS opt-in %zu: %s", p.lds, hipGetErrorString(e));
     }
     dim3 grid(p.nblk, p.qgroups);
+    vm_prof_scope prof(m->ctx, VM_PROF_TOPK_SCAN, st);
     kern<<<grid, SCAN_THREADS, p.lds, st>>>(m->rows, m->rnorm32, (const uint16_t *)queries, m->d_total, m->cap,
                                           m->ring, m->D, Q, p.q_pad, part_s, part_o);
     VM_LAUNCH_CHECK(m->ctx);
@@ -484,6 +485,7 @@ int run_topk(vm_memory *m, const ScanPlan &p, const void *queries, int Q, int k,
         default: rc = launch_scan_qt<DT, 64>(m, p, queries, Q, part_s, part_o, st); break;
     }
     if (rc != VM_OK) return rc;
+    vm_prof_scope prof(m->ctx, VM_PROF_TOPK_FINALIZE, st);
 #define FIN(KLV)                                                                                           \
     topk_finalize_kernel<DT, KLV><<<Q, FIN_THREADS, 0, st>>>(                                              \
         m->rows, m->norm64, (const uint16_t *)queries, m->d_total, m->cap, m->ring, m->D, p.q_pad, p.nblk, \
@@ -540,6 +542,7 @@ extern "C" int vm_topk_merge(vm_ctx *ctx, const double *scores, const int64_t *r
                              double *out_scores, int64_t *out_rows, void *stream) {
     if (!ctx || !scores || !rows || !out_scores || !out_rows || parts <= 0 || Q <= 0 || k <= 0)
         return vm_fail(ctx, VM_ERR_INVALID, "vm_topk_merge: bad arguments");
+    vm_prof_scope prof(ctx, VM_PROF_TOPK_MERGE, (hipStream_t)stream);
     topk_merge_kernel<<<Q, 256, 0, (hipStream_t)stream>>>(scores, rows, parts, Q, k, out_scores, out_rows);
     VM_LAUNCH_CHECK(ctx);
     return VM_OK;

@@ -160,6 +160,7 @@ extern "C" int vm_topk_cosine_exact(vm_memory *m, const void *queries, int Q, in
     if (!workspace || workspace_bytes < (size_t)Q * (size_t)(n > 0 ? n : 1) * 8)
         return vm_fail(ctx, VM_ERR_NOMEM, "vm_topk_cosine_exact: workspace too small");
     hipStream_t st = (hipStream_t)stream;
+    vm_prof_scope prof(ctx, VM_PROF_TOPK_EXACT, st);
     double *sc = (double *)workspace;
     if (n > 0) {
         dim3 grid((unsigned)((n + 255) / 256), Q);

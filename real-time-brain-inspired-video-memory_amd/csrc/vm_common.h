@@ -13,6 +13,29 @@ struct vm_ctx {
     int device;
     int num_cus;
     char err[512];
+    // optional per-kernel timing (vm_profile_enable): event pool, 2 events + 1 category per launch
+    hipEvent_t *prof_ev;
+    int *prof_cat;
+    int prof_cap, prof_n;
+    double prof_ms[VM_PROF_NCAT];
+    int64_t prof_launches[VM_PROF_NCAT];
+};
+
+// Brackets the launches inside a scope with two events when profiling is on; free when it is off.
+struct vm_prof_scope {
+    vm_ctx *ctx;
+    hipStream_t st;
+    int slot;
+    vm_prof_scope(vm_ctx *c, int cat, hipStream_t s) : ctx(c), st(s), slot(-1) {
+        if (c && c->prof_ev && c->prof_n < c->prof_cap) {
+            slot = c->prof_n++;
+            c->prof_cat[slot] = cat;
+            (void)hipEventRecord(c->prof_ev[2 * slot], s);
+        }
+    }
+    ~vm_prof_scope() {
+        if (slot >= 0) (void)hipEventRecord(ctx->prof_ev[2 * slot + 1], st);
+    }
 };
 
 inline int vm_fail(vm_ctx *ctx, int code, const char *fmt, ...) {

@@ -124,7 +124,8 @@ class EmbeddingMemory:
         if not exact and k <= 58:
             need = int(self.L.vm_topk_workspace_bytes(self.handle, Q, k))
             ws = self._workspace(need)
-            self._uncert.zero_()
+            if check_certified:
+                self._uncert.zero_()  # otherwise the counter keeps accumulating (read it with .item() later)
             self.ctx.check(self.L.vm_topk_cosine(
                 self.handle, C.c_void_p(q.data_ptr()), Q, k, use_min, ms, int(score_mode), int(row_stride),
                 int(row_offset), C.c_void_p(scores.data_ptr()), C.c_void_p(rows.data_ptr()),
