@@ -35,7 +35,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--chunks-per-step", type=int, default=16, help="chunks of 16 frames encoded per step per GPU")
+    ap.add_argument("--chunks-per-step", type=int, default=55,
+                    help="chunks of 16 frames encoded per step per GPU (55 chunks = 880 frames = 8 encoder passes of 110)")
     ap.add_argument("--memory-rows", type=int, default=100_000, help="rows of the memory shard per GPU")
     ap.add_argument("--topk", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -120,7 +121,8 @@ def main():
         step(i)
     torch.cuda.synchronize()
 
-    max_events = args.steps * 400 + 64
+    passes = -(-F // ((256 // (spec["hidden"] // 256)) * 256 // enc.tokens))
+    max_events = args.steps * (passes * (7 * spec["layers"] + 8) + 16) + 64
     ctx.profile_enable(max_events)
     if world > 1:
         dist.barrier()
@@ -160,7 +162,7 @@ def main():
         T = enc.tokens
         H, M = spec["hidden"], spec["mlp"]
         mbs = []  # micro-batch sizes vm_encode used for F frames (csrc/encoder.hip micro_batch_of)
-        mb = int(os.environ.get("VIDMEM_MICROBATCH", "0")) or 128
+        mb = int(os.environ.get("VIDMEM_MICROBATCH", "0")) or (256 // (H // 256)) * 256 // T
         left = F
         while left > 0:
             mbs.append(min(mb, left))

@@ -7,26 +7,31 @@
 //                     row max / row sum are register reductions plus two shuffles (xor 16, 32).
 //   P  = exp2(..)     fp32, masked keys -> 0, packed to 16-bit in exactly the B-operand order of the next MFMA
 //                     (k slot j<4 -> key 32ks+4h+j, j>=4 -> key 32ks+16+4h+j-4): no lane movement, no LDS.
-//   O^T = V^T . P^T   V^T[d][key] staged in LDS gives the A fragments with two ds_read_b64; the lane ends up with 4
-//                     consecutive d of one query -> 8-byte stores of the context row.
-// LDS: K tile [keys][64] with chunk ^= (key & 7) swizzle (conflict-free ds_read_b128); V^T rows padded to
-// 32*NS + 8 elements (row stride = 208 mod 256 bytes: conflict-free ds_read_b64).
+//   O^T = V^T . P^T   V stays ROW-major in LDS ([key][64 d], as it is in HBM); the A fragments (4 keys of one d per
+//                     lane) come from ds_read_b64_tr_b16, the CDNA4 transposing LDS read: per 16-lane group a
+//                     4-row x 16-column block, lane 4q+p supplies the address of row q / columns 4p..4p+3 and lane i
+//                     receives column i.  The lane ends up with 4 consecutive d of one query -> 8-byte context stores.
+// LDS: K and V tiles [keys][128 B] with the 16-byte chunk index XORed with (key & 7): conflict-free for the
+// ds_read_b128 K fragments and for the transposing V reads (8 consecutive keys per 32-lane half).
 #include "vm_internal.h"
 #include "vm_kernels.h"
 
 namespace {
 
+typedef short s4v __attribute__((__vector_size__(4 * sizeof(short))));
+typedef __attribute__((address_space(3))) s4v *lds_s4v_ptr;
+
 template <int DT, int NT>  // NT = key tiles of 16 (13 for 197 tokens, 37 for 577)
-__global__ void __launch_bounds__(256) attention_kernel(const uint16_t *__restrict__ qkv,
-                                                        uint16_t *__restrict__ ctx_out, int T, int heads) {
+__global__ void __launch_bounds__(256, (NT <= 13 ? 2 : 1))
+    attention_kernel(const uint16_t *__restrict__ qkv, uint16_t *__restrict__ ctx_out, int T, int heads) {
     using E = vm_elem<DT>;
     using vec8 = typename E::vec8;
-    constexpr int NS = (NT + 1) / 2;     // 32-key steps of the PV product
-    constexpr int VT_STRIDE = NS * 32 + 8;  // elements per V^T row
+    constexpr int NS = (NT + 1) / 2;  // 32-key steps of the PV product
     constexpr int KROWS = NT * 16;
+    constexpr int VROWS = NS * 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *kl = smem;                                                          // [KROWS][128 B]
-    uint16_t *vt = reinterpret_cast<uint16_t *>(smem + (size_t)KROWS * 128);  // [64][VT_STRIDE]
+    char *kl = smem;                         // [KROWS][128 B]
+    char *vl = smem + (size_t)KROWS * 128;   // [VROWS][128 B]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, h = lane >> 4;
@@ -35,24 +40,20 @@ __global__ void __launch_bounds__(256) attention_kernel(const uint16_t *__restri
     const size_t ld = (size_t)3 * H;
     const uint16_t *base = qkv + (size_t)b * T * ld + head * 64;
 
-    // ---- stage K (swizzled rows) and V^T ----------------------------------------------------------------
-    for (int idx = tid; idx < KROWS * 8; idx += 256) {
-        const int key = idx >> 3, c = idx & 7;
+    // ---- stage K and V rows (16-byte chunks, swizzled; rows past T are zero) -------------------------------
+    for (int idx = tid; idx < (KROWS + VROWS) * 8; idx += 256) {
+        const bool is_v = idx >= KROWS * 8;
+        const int i2 = is_v ? idx - KROWS * 8 : idx;
+        const int key = i2 >> 3, c = i2 & 7;
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (key < T) v = *reinterpret_cast<const uint4 *>(base + (size_t)key * ld + H + c * 8);
-        *reinterpret_cast<uint4 *>(kl + key * 128 + ((c ^ (key & 7)) << 4)) = v;
-    }
-    for (int idx = tid; idx < NS * 32 * 8; idx += 256) {
-        const int key = idx >> 3, c = idx & 7;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (key < T) v = *reinterpret_cast<const uint4 *>(base + (size_t)key * ld + 2 * H + c * 8);
-        const uint16_t *e = reinterpret_cast<const uint16_t *>(&v);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) vt[(c * 8 + i) * VT_STRIDE + key] = e[i];
+        if (key < T) v = *reinterpret_cast<const uint4 *>(base + (size_t)key * ld + (is_v ? 2 * H : H) + c * 8);
+        *reinterpret_cast<uint4 *>((is_v ? vl : kl) + key * 128 + ((c ^ (key & 7)) << 4)) = v;
     }
     __syncthreads();
 
     const float scale_log2e = 0.125f * 1.44269504088896340736f;  // 1/sqrt(64) * log2(e)
+    // transposing-read lane constants: lane i of a 16-lane group addresses row q = i>>2, columns 4p.. (p = i&3)
+    const int tq = r16 >> 2, tp = r16 & 3;
 
     for (int qt = wave; qt < NT; qt += 4) {
         int qtok = qt * 16 + r16;
@@ -87,7 +88,7 @@ __global__ void __launch_bounds__(256) attention_kernel(const uint16_t *__restri
         for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float e = exp2f(s[kt][j] - mx);
+                const float e = __builtin_amdgcn_exp2f(s[kt][j] - mx);
                 s[kt][j] = e;
                 sum += e;
             }
@@ -108,14 +109,20 @@ __global__ void __launch_bounds__(256) attention_kernel(const uint16_t *__restri
             }
             vec8 pf;
             __builtin_memcpy(&pf, pe, 16);
+            const int key_lo = ks * 32 + 4 * h + tq, key_hi = key_lo + 16;  // (key & 7) is the same for both
+            const char *row_lo = vl + key_lo * 128 + (tp & 1) * 8;
+            const int sw = key_lo & 7;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const uint16_t *vrow = vt + (dt * 16 + r16) * VT_STRIDE + ks * 32 + 4 * h;
-                uint2 lo = *reinterpret_cast<const uint2 *>(vrow);
-                uint2 hi = *reinterpret_cast<const uint2 *>(vrow + 16);
-                uint4 both = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                o[dt] = E::mfma16(__builtin_bit_cast(vec8, both), pf, o[dt]);
+                const int coff = ((2 * dt + (tp >> 1)) ^ sw) << 4;
+                const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr)(row_lo + coff));
+                const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr)(row_lo + 16 * 128 + coff));
+                short av[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                vec8 af;
+                __builtin_memcpy(&af, av, 16);
+                o[dt] = E::mfma16(af, pf, o[dt]);
             }
+            (void)key_hi;
         }
         if (qvalid) {
             uint16_t *dst = ctx_out + ((size_t)b * T + qtok) * H + head * 64 + 4 * h;
@@ -135,7 +142,7 @@ __global__ void __launch_bounds__(256) attention_kernel(const uint16_t *__restri
 template <int DT, int NT>
 int launch(vm_ctx *ctx, const uint16_t *qkv, uint16_t *out, int B, int T, int heads, hipStream_t st) {
     constexpr int NS = (NT + 1) / 2;
-    const size_t lds = (size_t)NT * 16 * 128 + (size_t)64 * (NS * 32 + 8) * 2;
+    const size_t lds = (size_t)NT * 16 * 128 + (size_t)NS * 32 * 128;
     auto kern = attention_kernel<DT, NT>;
     static bool attr_set = false;
     if (!attr_set) {

@@ -331,9 +331,18 @@ extern "C" int vm_encoder_patch_k(const vm_encoder *e) { return e ? e->patch_k :
 extern "C" int vm_encoder_out_dim(const vm_encoder *e) { return e ? e->out_dim : 0; }
 
 static int micro_batch_of(const vm_encoder *e, int B) {
-    // Frames per pass.  Large enough to fill 256 CUs with 128x128 GEMM tiles, small enough that one pass's
-    // activations (~1.3 MB/frame for ViT-B/16) stay inside the 256 MiB Infinity Cache between kernels.
-    int mb = e->micro_batch > 0 ? e->micro_batch : (e->d.hidden <= 768 ? 128 : 32);
+    // Frames per pass.  The GEMMs use 256 x 256 tiles, one per CU per round: pick the largest batch whose token rows
+    // fill a whole number of rounds for the narrowest GEMM (N = hidden): ceil(mb*T/256) * (hidden/256) <= ~CUs.
+    // ViT-B/16 (T=197, hidden 768): 85 row tiles x 3 = 255 tiles -> 110 frames; CLIP-L/14-336 (T=577, hidden 1024):
+    // 64 x 4 = 256 tiles -> 28 frames.  One pass's activations (~1.5 MB/frame for ViT-B/16) also stay close to the
+    // 256 MiB Infinity Cache between kernels.
+    int mb = e->micro_batch;
+    if (mb <= 0) {
+        const int col_tiles = e->d.hidden / 256;
+        const int row_tiles = e->ctx->num_cus / col_tiles;
+        mb = row_tiles * 256 / e->tokens;
+        if (mb < 1) mb = 1;
+    }
     return B < mb ? B : mb;
 }
 

@@ -1,24 +1,28 @@
 // Dense layers of the vision encoder: out[t, f] = sum_k X[t, k] * W[f, k] (+ fused epilogue), 16-bit operands,
 // fp32 MFMA accumulation.  MFMA-bound: 95.9 % (ViT-B/16) / 91.4 % (CLIP-L/14-336) of the encoder's FLOPs run here.
 //
-// Tile 128 (features) x 128 (tokens) x 64 (k) per 256-thread workgroup, 4 waves as 2 x 2, each wave 64 x 64 =
-// 4 x 4 tiles of v_mfma_f32_16x16x32.  The WEIGHT tile is the MFMA A operand and the ACTIVATION tile the B
-// operand, so a lane ends up with 4 consecutive features of one token: epilogue stores are 8-byte (16-bit out)
-// or 16-byte (fp32 residual) row pieces with no LDS transpose.
-// Staging: global_load_lds_dwordx4 (16 B/lane, 1 KiB per wave instruction = 8 rows x 128 B) into a linear LDS
-// image, double buffered; the XOR swizzle chunk ^= (row & 7) is applied on the per-lane SOURCE address and again
-// on the ds_read_b128 address (both sides or neither), which makes the fragment reads bank-conflict free.
-// Workgroups are renumbered so that the column tiles of one token panel land on the same XCD (its L2 then serves
-// the panel's re-reads).
+// In both kernels the WEIGHT tile is the MFMA A operand and the ACTIVATION tile the B operand, so a lane ends up
+// with 4 consecutive features of one token: epilogue stores are 8-byte (16-bit out) or 16-byte (fp32 residual) row
+// pieces with no LDS transpose.  Staging is global_load_lds_dwordx4 (16 B/lane, 1 KiB per wave instruction = 8 rows
+// x 128 B) into a linear LDS image; the XOR swizzle chunk ^= (row & 7) is applied on the per-lane SOURCE address and
+// again on the ds_read_b128 address (both sides or neither), which makes the fragment reads bank-conflict free.
+// Workgroups are renumbered so that the feature tiles of one token panel land on the same XCD (its L2 then serves the
+// panel's re-reads).
+//
+//   gemm256_kernel  256 (features) x 256 (tokens) x 64 tile, 8 waves (2 x 4), one workgroup per CU (128 KiB LDS).
+//                   Each K-tile runs as 4 phases of {ds_read fragments | 16 MFMA}, separated by raw s_barriers; the
+//                   two wave rows are offset by one barrier, so on every SIMD one wave issues MFMAs while its partner
+//                   reads LDS / issues the next K-tile's LDS-DMA.  The next K-tile is staged into the other LDS buffer
+//                   2 instructions per phase and retired region by region with counted vmcnt waits.
+//   gemm128_kernel  128 x 128 x 64 tile, 4 waves, two workgroups per CU: used when a 256-row tile grid would leave
+//                   most CUs idle (small batches).
 #include "vm_internal.h"
 #include "vm_kernels.h"
 
 namespace {
 
-constexpr int BM = 128;  // tokens per tile
-constexpr int BN = 128;  // features per tile
 constexpr int BK = 64;
-constexpr int TILE_BYTES = 128 * BK * 2;  // one operand tile, 16 KiB
+constexpr int HALF_BYTES = 128 * BK * 2;  // 128 rows x 64 k, 16 KiB
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *gbl_ptr_t;
@@ -26,41 +30,277 @@ typedef const __attribute__((address_space(1))) void *gbl_ptr_t;
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
 
+// XCD-aware renumbering (bijective for any grid size): ids that share (blockIdx % 8) become neighbours.
+__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
+    const int xcd = orig & 7, qd = nwg >> 3, rm = nwg & 7;
+    return (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (orig >> 3);
+}
+
+// Epilogue of one token row t for NI feature tiles of a wave: the lane owns features fbase + 16*i + [0,4).
+// All loads (bias, residual / position rows) are issued before the first use so they overlap instead of
+// serialising on one s_waitcnt each.
+template <int DT, int EPI, int NI>
+__device__ __forceinline__ void epilogue_row(const GemmArgs &g, const f32x4 (&a)[NI], int t, int fbase) {
+    using E = vm_elem<DT>;
+    float4 b4[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) b4[i] = *reinterpret_cast<const float4 *>(g.bias + fbase + 16 * i);
+    if (EPI == EPI_STORE16 || EPI == EPI_GELU16 || EPI == EPI_QGELU16) {
+        uint16_t *orow = g.out16 + (size_t)t * g.ldo + fbase;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            float v[4] = {a[i][0] + b4[i].x, a[i][1] + b4[i].y, a[i][2] + b4[i].z, a[i][3] + b4[i].w};
+            uint16_t o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float y = v[e];
+                if (EPI == EPI_GELU16) y = gelu_erf(y);
+                if (EPI == EPI_QGELU16) y = quick_gelu(y);
+                o[e] = E::from_float(y);
+            }
+            uint2 pk;
+            __builtin_memcpy(&pk, o, 8);
+            *reinterpret_cast<uint2 *>(orow + 16 * i) = pk;
+        }
+    } else if (EPI == EPI_RESID32) {
+        float *orow = g.out32 + (size_t)t * g.ldo + fbase;
+        float4 r[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) r[i] = *reinterpret_cast<const float4 *>(orow + 16 * i);
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            *reinterpret_cast<float4 *>(orow + 16 * i) =
+                make_float4(r[i].x + (a[i][0] + b4[i].x), r[i].y + (a[i][1] + b4[i].y), r[i].z + (a[i][2] + b4[i].z),
+                            r[i].w + (a[i][3] + b4[i].w));
+    } else {  // EPI_PATCH: GEMM row = frame*P + p  ->  token row frame*T + 1 + p, plus pos[1 + p]
+        const int fr = t / g.P, p = t - fr * g.P;
+        const float *prow = g.pos + (size_t)(1 + p) * g.N + fbase;
+        float *orow = g.out32 + ((size_t)fr * g.T + 1 + p) * g.ldo + fbase;
+        float4 r[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) r[i] = *reinterpret_cast<const float4 *>(prow + 16 * i);
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            *reinterpret_cast<float4 *>(orow + 16 * i) =
+                make_float4((a[i][0] + b4[i].x) + r[i].x, (a[i][1] + b4[i].y) + r[i].y, (a[i][2] + b4[i].z) + r[i].z,
+                            (a[i][3] + b4[i].w) + r[i].w);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 256 x 256 x 64, 8 waves, 4 phases per K-tile
+// ---------------------------------------------------------------------------------------------------------------
+template <int DT, int EPI, int ABL = 0>  // ABL: developer ablation bits (1 no LDS-DMA in loop, 2 no ds_read, 4 no MFMA)
+__global__ void __launch_bounds__(512, 1) gemm256_kernel(GemmArgs g) {
+    using E = vm_elem<DT>;
+    using vec8 = typename E::vec8;
+    // [2 buffers][W half0 | W half1 | X half0 | X half1], each half 128 rows x 128 B
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, h = lane >> 4;
+    const int tiles_n = g.N >> 8;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    const int t0 = tm << 8, f0 = tn << 8;
+    const int wr = wave >> 2, wc = wave & 3;  // wave row: 128 features; wave column: 64 tokens
+    const int K = g.K, M = g.M;
+
+    // staging: per K-tile every wave issues 8 LDS-DMA instructions of 8 rows x 128 B, two from each REGION, where a
+    // region is the set of rows all waves read in the same phase:
+    //   Wa0 = W rows {0..63, 128..191} (phase 1)   Wa1 = W rows {64..127, 192..255} (phase 3)
+    //   Xb0 = X rows {64c + 0..31}     (phase 1)   Xb1 = X rows {64c + 32..63}      (phase 2)      c = 0..3
+    // 8-row block q = 2*wave + u (u = 0, 1) of a region; LDS byte offset of tile row r is r * 128.
+    const int srow = lane >> 3, scp = lane & 7;
+    const uint16_t *src_wa0[2], *src_wa1[2], *src_xb0[2], *src_xb1[2];
+    int lds_wa0[2], lds_xb0[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int q = 2 * wave + u;
+        const int wrow0 = (q < 8 ? q * 8 : 128 + (q - 8) * 8);  // first row of the block in Wa0; Wa1 = +64
+        const int xrow0 = (q >> 2) * 64 + (q & 3) * 8;          // first row of the block in Xb0; Xb1 = +32
+        const int wrow = wrow0 + srow, xrow = xrow0 + srow;     // (row & 7) == srow in every region
+        const int chunk = scp ^ srow;
+        src_wa0[u] = g.W + (size_t)(f0 + wrow) * K + chunk * 8;
+        src_wa1[u] = g.W + (size_t)(f0 + wrow + 64) * K + chunk * 8;
+        int t_b0 = t0 + xrow, t_b1 = t0 + xrow + 32;
+        if (t_b0 > M - 1) t_b0 = M - 1;
+        if (t_b1 > M - 1) t_b1 = M - 1;
+        src_xb0[u] = g.X + (size_t)t_b0 * g.ldx + chunk * 8;
+        src_xb1[u] = g.X + (size_t)t_b1 * g.ldx + chunk * 8;
+        lds_wa0[u] = wrow0 * 128;
+        lds_xb0[u] = 2 * HALF_BYTES + xrow0 * 128;
+    }
+    auto dma2 = [&](const uint16_t *const (&src)[2], const int (&dst)[2], int extra, int kt, int buf) {
+        if ((ABL & 1) && kt > 0) return;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[u] + kt * BK),
+                                             (lds_ptr_t)(smem + buf * 4 * HALF_BYTES + dst[u] + extra), 16, 0, 0);
+    };
+    auto stage_Wa0 = [&](int kt, int buf) { dma2(src_wa0, lds_wa0, 0, kt, buf); };
+    auto stage_Wa1 = [&](int kt, int buf) { dma2(src_wa1, lds_wa0, 64 * 128, kt, buf); };
+    auto stage_Xb0 = [&](int kt, int buf) { dma2(src_xb0, lds_xb0, 0, kt, buf); };
+    auto stage_Xb1 = [&](int kt, int buf) { dma2(src_xb1, lds_xb0, 32 * 128, kt, buf); };
+
+    // fragment read addresses inside one buffer (byte offsets); row & 7 == r16 & 7 for every 16-row tile
+    const int sw0 = ((h ^ (r16 & 7)) << 4), sw1 = (((h + 4) ^ (r16 & 7)) << 4);
+    const int a_base = (wr * 128 + r16) * 128;                       // + i*16*128, i = 0..7
+    const int b_base = 2 * HALF_BYTES + (wc * 64 + r16) * 128;       // + j*16*128, j = 0..3
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    vec8 af[4][2], bf[4][2];  // af: current half (4 feature tiles) x 2 k-substeps; bf: all 4 token tiles
+
+    auto read_a = [&](const char *buf, int half) {
+        if ((ABL & 2) && buf != smem) return;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const char *p = buf + a_base + (half * 4 + i) * 2048;
+            af[i][0] = *reinterpret_cast<const vec8 *>(p + sw0);
+            af[i][1] = *reinterpret_cast<const vec8 *>(p + sw1);
+        }
+    };
+    auto read_b = [&](const char *buf, int half) {
+        if ((ABL & 2) && buf != smem) return;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const char *p = buf + b_base + (half * 2 + j) * 2048;
+            bf[half * 2 + j][0] = *reinterpret_cast<const vec8 *>(p + sw0);
+            bf[half * 2 + j][1] = *reinterpret_cast<const vec8 *>(p + sw1);
+        }
+    };
+    auto mma = [&](int ahalf, int bhalf) {
+        if (ABL & 4) return;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[ahalf * 4 + i][bhalf * 2 + j] =
+                        E::mfma16(af[i][s], bf[bhalf * 2 + j][s], acc[ahalf * 4 + i][bhalf * 2 + j]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+#define VM_BAR() __builtin_amdgcn_s_barrier()
+#define VM_LGKM0()                                         \
+    do {                                                   \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        __builtin_amdgcn_sched_barrier(0);                 \
+    } while (0)
+
+    // LDS-DMA of K-tile kt+1 is spread over the four phases of K-tile kt, 2 instructions each, issue order
+    // Wa0, Xb0, Xb1, Wa1.  Each region is retired by a COUNTED wait placed before the first barrier of the phase
+    // that precedes its first read (never vmcnt(0) in the steady state):
+    //   phase 4 of kt  : vmcnt(4) leaves {Xb1, Wa1} in flight, retires Wa0 + Xb0 -> read in phase 1 of kt+1
+    //   phase 1 of kt+1: vmcnt(4) after issuing the next Wa0: retires Xb1          -> read in phase 2
+    //   phase 2 of kt+1: vmcnt(4) after issuing the next Xb0: retires Wa1          -> read in phase 3
+    const int nk = K / BK;
+    stage_Wa0(0, 0);
+    stage_Xb0(0, 0);
+    stage_Xb1(0, 0);
+    stage_Wa1(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    VM_BAR();
+    if (wr == 1) VM_BAR();  // wave row 1 runs one barrier behind wave row 0
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const char *buf = smem + (kt & 1) * 4 * HALF_BYTES;
+        const bool more = kt + 1 < nk;
+        const int nb = (kt + 1) & 1;
+        // phase 1
+        read_a(buf, 0);
+        read_b(buf, 0);
+        if (more) {
+            stage_Wa0(kt + 1, nb);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        VM_BAR();
+        VM_LGKM0();
+        mma(0, 0);
+        VM_BAR();
+        // phase 2
+        read_b(buf, 1);
+        if (more) {
+            stage_Xb0(kt + 1, nb);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        }
+        VM_BAR();
+        VM_LGKM0();
+        mma(0, 1);
+        VM_BAR();
+        // phase 3
+        read_a(buf, 1);
+        if (more) stage_Xb1(kt + 1, nb);
+        VM_BAR();
+        VM_LGKM0();
+        mma(1, 1);
+        VM_BAR();
+        // phase 4
+        if (more) {
+            stage_Wa1(kt + 1, nb);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        }
+        VM_BAR();
+        mma(1, 0);
+        VM_BAR();
+    }
+    if (wr == 0) VM_BAR();  // match wave row 1's extra barrier
+#undef VM_BAR
+#undef VM_LGKM0
+
+    // epilogue: acc[i][j][e] = out[token t0 + wc*64 + 16j + r16][feature f0 + wr*128 + 16i + 4h + e]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int t = t0 + wc * 64 + j * 16 + r16;
+        if (t >= M) continue;
+        f32x4 col[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) col[i] = acc[i][j];
+        epilogue_row<DT, EPI, 8>(g, col, t, f0 + wr * 128 + 4 * h);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 128 x 128 x 64, 4 waves (2 x 2), double-buffered, one barrier per K-tile
+// ---------------------------------------------------------------------------------------------------------------
 template <int DT, int EPI>
-__global__ void __launch_bounds__(256, 2) gemm_kernel(GemmArgs g) {
+__global__ void __launch_bounds__(256, 2) gemm128_kernel(GemmArgs g) {
     using E = vm_elem<DT>;
     using vec8 = typename E::vec8;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][W tile | X tile]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, h = lane >> 4;
-    const int tiles_n = g.N / BN;
-    // XCD-aware renumbering (bijective for any grid size): ids that share (blockIdx % 8) become neighbours
-    const int nwg = gridDim.x, orig = blockIdx.x;
-    const int xcd = orig & 7, qd = nwg >> 3, rm = nwg & 7;
-    const int bid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (orig >> 3);
+    const int tiles_n = g.N >> 7;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
-    const int t0 = tm * BM, f0 = tn * BN;
+    const int t0 = tm << 7, f0 = tn << 7;
     const int wf = wave & 1, wt = wave >> 1;
-
-    const uint16_t *W = g.W, *X = g.X;
     const int K = g.K, M = g.M;
 
-    // per-lane staging sources: wave w stages rows [32w, 32w+32) of both tiles, 4 instructions x 8 rows
     const int srow = lane >> 3, scp = lane & 7;
     const uint16_t *wsrc[4], *xsrc[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int row = wave * 32 + u * 8 + srow;
         const int chunk = scp ^ (row & 7);
-        wsrc[u] = W + (size_t)(f0 + row) * K + chunk * 8;
+        wsrc[u] = g.W + (size_t)(f0 + row) * K + chunk * 8;
         int tr = t0 + row;
         if (tr > M - 1) tr = M - 1;
-        xsrc[u] = X + (size_t)tr * g.ldx + chunk * 8;
+        xsrc[u] = g.X + (size_t)tr * g.ldx + chunk * 8;
     }
     auto stage = [&](int kt, int buf) {
-        char *wl = smem + buf * 2 * TILE_BYTES + wave * 32 * 128;
-        char *xl = wl + TILE_BYTES;
+        char *wl = smem + buf * 2 * HALF_BYTES + wave * 32 * 128;
+        char *xl = wl + HALF_BYTES;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(wsrc[u] + kt * BK), (lds_ptr_t)(wl + u * 1024), 16, 0, 0);
@@ -81,18 +321,18 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmArgs g) {
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
-        const char *wl = smem + buf * 2 * TILE_BYTES;
-        const char *xl = wl + TILE_BYTES;
+        const char *wl = smem + buf * 2 * HALF_BYTES;
+        const char *xl = wl + HALF_BYTES;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             vec8 wf_[4], xf_[4];
             const int c = h + 4 * s;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int wr = wf * 64 + i * 16 + r16;
-                wf_[i] = *reinterpret_cast<const vec8 *>(wl + wr * 128 + ((c ^ (wr & 7)) << 4));
-                const int xr = wt * 64 + i * 16 + r16;
-                xf_[i] = *reinterpret_cast<const vec8 *>(xl + xr * 128 + ((c ^ (xr & 7)) << 4));
+                const int wrow = wf * 64 + i * 16 + r16;
+                wf_[i] = *reinterpret_cast<const vec8 *>(wl + wrow * 128 + ((c ^ (wrow & 7)) << 4));
+                const int xrow = wt * 64 + i * 16 + r16;
+                xf_[i] = *reinterpret_cast<const vec8 *>(xl + xrow * 128 + ((c ^ (xrow & 7)) << 4));
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -102,89 +342,92 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmArgs g) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
-
-    // epilogue: acc[i][j][e] = out[token t0 + wt*64 + 16j + r16][feature f0 + wf*64 + 16i + 4h + e]
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int t = t0 + wt * 64 + j * 16 + r16;
         if (t >= M) continue;
-        size_t orow = (size_t)t;
-        const float *pos = nullptr;
-        if (EPI == EPI_PATCH) {  // GEMM row = frame*P + p  ->  token row frame*T + 1 + p, plus pos[1 + p]
-            const int fr = t / g.P, p = t - fr * g.P;
-            orow = (size_t)fr * g.T + 1 + p;
-            pos = g.pos + (size_t)(1 + p) * g.N;
-        }
+        f32x4 col[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int f = f0 + wf * 64 + i * 16 + 4 * h;
-            const float4 b4 = *reinterpret_cast<const float4 *>(g.bias + f);
-            float v[4] = {acc[i][j][0] + b4.x, acc[i][j][1] + b4.y, acc[i][j][2] + b4.z, acc[i][j][3] + b4.w};
-            if (EPI == EPI_STORE16 || EPI == EPI_GELU16 || EPI == EPI_QGELU16) {
-                uint16_t o[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float y = v[e];
-                    if (EPI == EPI_GELU16) y = gelu_erf(y);
-                    if (EPI == EPI_QGELU16) y = quick_gelu(y);
-                    o[e] = E::from_float(y);
-                }
-                uint2 pk;
-                __builtin_memcpy(&pk, o, 8);
-                *reinterpret_cast<uint2 *>(g.out16 + orow * g.ldo + f) = pk;
-            } else if (EPI == EPI_RESID32) {
-                float4 *dst = reinterpret_cast<float4 *>(g.out32 + orow * g.ldo + f);
-                float4 r = *dst;
-                r.x += v[0];
-                r.y += v[1];
-                r.z += v[2];
-                r.w += v[3];
-                *dst = r;
-            } else {  // EPI_PATCH
-                const float4 p4 = *reinterpret_cast<const float4 *>(pos + f);
-                *reinterpret_cast<float4 *>(g.out32 + orow * g.ldo + f) =
-                    make_float4(v[0] + p4.x, v[1] + p4.y, v[2] + p4.z, v[3] + p4.w);
-            }
-        }
+        for (int i = 0; i < 4; ++i) col[i] = acc[i][j];
+        epilogue_row<DT, EPI, 4>(g, col, t, f0 + wf * 64 + 4 * h);
     }
 }
 
-template <int DT>
-int launch(vm_ctx *ctx, const GemmArgs &g, int epi, hipStream_t st) {
-    const int tiles = ((g.M + BM - 1) / BM) * (g.N / BN);
-    const size_t lds = 4 * TILE_BYTES;
-    const int cat = epi == EPI_PATCH ? VM_PROF_GEMM_PATCH
-                    : epi == EPI_STORE16 ? VM_PROF_GEMM_QKV
-                    : epi == EPI_RESID32 ? VM_PROF_GEMM_RESID : VM_PROF_GEMM_ACT;
-    vm_prof_scope prof(ctx, cat, st);
-#define GO(EPIV)                                                                                            \
-    do {                                                                                                    \
-        auto kern = gemm_kernel<DT, EPIV>;                                                                  \
-        static bool attr_set = false;                                                                       \
-        if (!attr_set) {                                                                                    \
-            VM_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                            (int)lds));                                                     \
-            attr_set = true;                                                                                \
-        }                                                                                                   \
-        kern<<<tiles, 256, lds, st>>>(g);                                                                   \
-    } while (0)
-    switch (epi) {
-        case EPI_STORE16: GO(EPI_STORE16); break;
-        case EPI_GELU16: GO(EPI_GELU16); break;
-        case EPI_QGELU16: GO(EPI_QGELU16); break;
-        case EPI_RESID32: GO(EPI_RESID32); break;
-        case EPI_PATCH: GO(EPI_PATCH); break;
-        default: return vm_fail(ctx, VM_ERR_INVALID, "bad epilogue %d", epi);
+int g_variant = 0;  // 0 auto, 1 force 128^2, 2 force 256^2 (tools/gemm_bench, VIDMEM_GEMM)
+
+template <int DT, int EPI>
+int launch_epi(vm_ctx *ctx, const GemmArgs &g, hipStream_t st) {
+    static int env_variant = -1;
+    if (env_variant < 0) {
+        const char *e = getenv("VIDMEM_GEMM");
+        env_variant = e ? atoi(e) : 0;
     }
-#undef GO
+    const int variant = g_variant ? g_variant : env_variant;
+    const int tiles256 = ((g.M + 255) / 256) * (g.N / 256);
+    const bool big_ok = g.N % 256 == 0;
+    // a 256^2 grid must give (nearly) every CU a tile; below that the 128^2 kernel fills the chip better
+    const bool use256 = variant == 2 ? big_ok : (variant == 1 ? false : (big_ok && tiles256 * 10 >= ctx->num_cus * 8));
+#ifdef VM_GEMM_ABLATE
+    if (variant >= 16 && EPI == EPI_STORE16 && DT == VM_F16) {
+        const size_t lds = 8 * HALF_BYTES;
+        const int abl = variant >> 4;
+#define ABLGO(A)                                                                                                  \
+    case A: {                                                                                                     \
+        auto k = gemm256_kernel<VM_F16, EPI_STORE16, A>;                                                          \
+        (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
+        k<<<tiles256, 512, lds, st>>>(g);                                                                         \
+    } break;
+        switch (abl) { ABLGO(1) ABLGO(2) ABLGO(3) ABLGO(4) ABLGO(5) ABLGO(6) ABLGO(7) default: break; }
+#undef ABLGO
+        VM_LAUNCH_CHECK(ctx);
+        return VM_OK;
+    }
+#endif
+    if (use256) {
+        auto kern = gemm256_kernel<DT, EPI>;
+        static bool attr_set = false;
+        const size_t lds = 8 * HALF_BYTES;
+        if (!attr_set) {
+            VM_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        kern<<<tiles256, 512, lds, st>>>(g);
+    } else {
+        auto kern = gemm128_kernel<DT, EPI>;
+        static bool attr_set = false;
+        const size_t lds = 4 * HALF_BYTES;
+        if (!attr_set) {
+            VM_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        kern<<<((g.M + 127) / 128) * (g.N / 128), 256, lds, st>>>(g);
+    }
     VM_LAUNCH_CHECK(ctx);
     return VM_OK;
 }
 
+template <int DT>
+int launch(vm_ctx *ctx, const GemmArgs &g, int epi, hipStream_t st) {
+    const int cat = epi == EPI_PATCH ? VM_PROF_GEMM_PATCH
+                    : epi == EPI_STORE16 ? VM_PROF_GEMM_QKV
+                    : epi == EPI_RESID32 ? VM_PROF_GEMM_RESID : VM_PROF_GEMM_ACT;
+    vm_prof_scope prof(ctx, cat, st);
+    switch (epi) {
+        case EPI_STORE16: return launch_epi<DT, EPI_STORE16>(ctx, g, st);
+        case EPI_GELU16: return launch_epi<DT, EPI_GELU16>(ctx, g, st);
+        case EPI_QGELU16: return launch_epi<DT, EPI_QGELU16>(ctx, g, st);
+        case EPI_RESID32: return launch_epi<DT, EPI_RESID32>(ctx, g, st);
+        case EPI_PATCH: return launch_epi<DT, EPI_PATCH>(ctx, g, st);
+        default: return vm_fail(ctx, VM_ERR_INVALID, "bad epilogue %d", epi);
+    }
+}
+
 }  // namespace
 
+void vm_gemm_set_variant(int v) { g_variant = v; }
+
 int vm_gemm(vm_ctx *ctx, int dtype, const GemmArgs &g, int epi, hipStream_t st) {
-    if (g.M <= 0 || g.N % BN != 0 || g.K % BK != 0 || g.K <= 0)
+    if (g.M <= 0 || g.N % 128 != 0 || g.K % BK != 0 || g.K <= 0)
         return vm_fail(ctx, VM_ERR_UNSUPPORTED, "gemm shape M=%d N=%d K=%d (need N%%128==0, K%%64==0)", g.M, g.N,
                        g.K);
     return dtype == VM_F16 ? launch<VM_F16>(ctx, g, epi, st) : launch<VM_BF16>(ctx, g, epi, st);

@@ -1,0 +1,9 @@
+#!/bin/bash
+# Developer helper: rebuild libvidmem.so and the GEMM harness (absolute paths; safe from any cwd).
+set -e
+R=/root/repo
+P=$R/real-time-brain-inspired-video-memory_amd
+make -s -j8 -C $P/csrc 2>&1 | grep -E "error|warning: unused|Error" -A5 || true
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -c $R/tools/gemm_bench.hip -o /tmp/gemm_bench.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 /tmp/gemm_bench.o $P/csrc/gemm.o $P/csrc/context.o -o $R/tools/bin/gemm_bench
+ls -la $R/tools/bin/gemm_bench $P/libvidmem.so

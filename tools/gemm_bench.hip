@@ -1,0 +1,69 @@
+// Developer harness (not part of libvidmem): correctness + timing of the encoder GEMM kernels on random data.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_bench.hip <pkg>/csrc/gemm.o <pkg>/csrc/context.o -o gpurun_out/gemm_bench
+//   gemm_bench M N K [epi] [iters]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <cmath>
+#include "../real-time-brain-inspired-video-memory_amd/csrc/vm_kernels.h"
+void vm_gemm_set_variant(int v);
+
+__global__ void ref_gemm(const _Float16 *X, const _Float16 *W, const float *bias, float *C, int M, int N, int K) {
+    int f = blockIdx.x * blockDim.x + threadIdx.x, t = blockIdx.y;
+    if (f >= N) return;
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) acc += (float)X[(size_t)t * K + k] * (float)W[(size_t)f * K + k];
+    C[(size_t)t * N + f] = acc + bias[f];
+}
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+
+int main(int argc, char **argv) {
+    int M = argc > 1 ? atoi(argv[1]) : 21670, N = argc > 2 ? atoi(argv[2]) : 3072, K = argc > 3 ? atoi(argv[3]) : 768;
+    int epi = argc > 4 ? atoi(argv[4]) : EPI_STORE16, iters = argc > 5 ? atoi(argv[5]) : 20;
+    vm_ctx *ctx; if (vm_init(0, &ctx)) { printf("vm_init failed: %s\n", vm_last_error(nullptr)); return 1; }
+    std::vector<_Float16> hx((size_t)M * K), hw((size_t)N * K); std::vector<float> hb(N);
+    srand(1);
+    for (auto &v : hx) v = (_Float16)(rand() / (float)RAND_MAX * 2.f - 1.f);
+    for (auto &v : hw) v = (_Float16)((rand() / (float)RAND_MAX * 2.f - 1.f) * 0.05f);
+    for (auto &v : hb) v = rand() / (float)RAND_MAX - 0.5f;
+    _Float16 *dx, *dw, *dout16; float *db, *dref, *dout32;
+    CK(hipMalloc(&dx, hx.size() * 2)); CK(hipMalloc(&dw, hw.size() * 2)); CK(hipMalloc(&db, N * 4));
+    CK(hipMalloc(&dref, (size_t)M * N * 4)); CK(hipMalloc(&dout16, (size_t)M * N * 2)); CK(hipMalloc(&dout32, (size_t)M * N * 4));
+    CK(hipMemcpy(dx, hx.data(), hx.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dw, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(db, hb.data(), N * 4, hipMemcpyHostToDevice));
+    ref_gemm<<<dim3((N + 255) / 256, M), 256>>>(dx, dw, db, dref, M, N, K);
+    CK(hipDeviceSynchronize());
+    std::vector<float> href((size_t)M * N); CK(hipMemcpy(href.data(), dref, href.size() * 4, hipMemcpyDeviceToHost));
+    GemmArgs g{}; g.X = (const uint16_t *)dx; g.W = (const uint16_t *)dw; g.bias = db; g.out16 = (uint16_t *)dout16; g.out32 = dout32;
+    g.M = M; g.N = N; g.K = K; g.ldx = K; g.ldo = N;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    int vlist[] = {1, 2, 2 + 16, 2 + 32, 2 + 48, 2 + 64, 2 + 80, 2 + 112};
+    int nv = getenv("ABLATE") ? 8 : 2;
+    for (int vi = 0; vi < nv; ++vi) {
+        int variant = vlist[vi];
+        if (variant >= 2 && N % 256) continue;
+        vm_gemm_set_variant(variant);
+        CK(hipMemset(dout16, 0, (size_t)M * N * 2)); CK(hipMemset(dout32, 0, (size_t)M * N * 4));
+        if (vm_gemm(ctx, VM_F16, g, epi, 0)) { printf("vm_gemm: %s\n", vm_last_error(ctx)); return 1; }
+        CK(hipDeviceSynchronize());
+        double maxerr = 0, maxref = 0; size_t bad = 0;
+        if (epi == EPI_STORE16) {
+            std::vector<_Float16> ho((size_t)M * N); CK(hipMemcpy(ho.data(), dout16, ho.size() * 2, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < ho.size(); ++i) { double d = fabs((double)ho[i] - href[i]); if (d > maxerr) maxerr = d; if (fabs(href[i]) > maxref) maxref = fabs(href[i]); if (d > 2e-3 * (1 + fabs(href[i]))) ++bad; }
+        } else {
+            std::vector<float> ho((size_t)M * N); CK(hipMemcpy(ho.data(), dout32, ho.size() * 4, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < ho.size(); ++i) { double d = fabs((double)ho[i] - href[i]); if (d > maxerr) maxerr = d; if (fabs(href[i]) > maxref) maxref = fabs(href[i]); if (d > 2e-4 * (1 + fabs(href[i]))) ++bad; }
+        }
+        for (int i = 0; i < 3; ++i) vm_gemm(ctx, VM_F16, g, epi, 0);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0, 0));
+        for (int i = 0; i < iters; ++i) vm_gemm(ctx, VM_F16, g, epi, 0);
+        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
+        printf("M=%d N=%d K=%d epi=%d variant=%s: %.1f us  %.0f TFLOP/s  maxerr %.3g (ref max %.3g) bad=%zu\n", M, N, K, epi,
+               variant == 1 ? "128^2" : (variant == 2 ? "256^2" : (variant == 18 ? "256 noDMA" : variant == 34 ? "256 noDSREAD" : variant == 50 ? "256 noDMA noDSREAD" : variant == 66 ? "256 noMFMA" : variant == 82 ? "256 noDMA noMFMA" : "256 none")), ms * 1e3, 2.0 * M * N * K / (ms * 1e-3) / 1e12, maxerr, maxref, bad);
+    }
+    return 0;
+}
