@@ -13,8 +13,9 @@ this oracle instead (tests/golden/make_vit_golden.py, run in the authoring conta
 Two modes:
   quant=None        plain fp32 forward (the "what the model means" answer)
   quant="f16"/"bf16" same forward with a round-to-dtype at exactly the points where the HIP path stores a
-                    16-bit value (weights, pixels, LN outputs, QKV, softmax numerators, context, GELU
-                    output, final embedding) - fp32 everywhere else, like the kernels' accumulators.
+                    16-bit value (weights, pixels, patch-embed rows, LN outputs, QKV, softmax numerators, context,
+                    attention-projection and FC2 outputs, GELU output, final embedding) - fp32 everywhere else,
+                    like the kernels' accumulators and the residual stream.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
 """
@@ -91,6 +92,7 @@ def vit_forward_ref(spec: Dict, w: Dict[str, np.ndarray], pixels_chw, quant: Opt
     tok = patches @ qw(w["patch_w"]).T
     if spec["patch_bias"]:
         tok = tok + t(w["patch_b"])
+    tok = _q(tok, quant)  # the patch GEMM stores 16-bit rows; pos / cls are added in fp32 afterwards
     cls = t(w["cls"]).reshape(1, 1, H).expand(B, 1, H)
     x = torch.cat([cls, tok], dim=1) + t(w["pos"]).unsqueeze(0)  # fp32 residual stream
     if spec["pre_ln"]:
@@ -111,10 +113,10 @@ def vit_forward_ref(spec: Dict, w: Dict[str, np.ndarray], pixels_chw, quant: Opt
         den = e.sum(dim=-1, keepdim=True)  # fp32 sum of the unquantised numerators
         ctx = (_q(e, quant) @ v) / den
         ctx = _q(ctx.transpose(1, 2).reshape(B, N, H), quant)
-        x = x + (ctx @ qw(p("proj_w")).T + t(p("proj_b")))
+        x = x + _q(ctx @ qw(p("proj_w")).T + t(p("proj_b")), quant)  # 16-bit branch output, fp32 residual
         h = _q(_layernorm(x, t(p("ln2_g")), t(p("ln2_b")), spec["ln_eps"]), quant)
         a = _q(_act(h @ qw(p("fc1_w")).T + t(p("fc1_b")), spec["act"]), quant)
-        x = x + (a @ qw(p("fc2_w")).T + t(p("fc2_b")))
+        x = x + _q(a @ qw(p("fc2_w")).T + t(p("fc2_b")), quant)
     if return_tokens:
         return _layernorm(x, t(w["ln_g"]), t(w["ln_b"]), spec["ln_eps"]).numpy()
     pooled = _layernorm(x[:, 0], t(w["ln_g"]), t(w["ln_b"]), spec["ln_eps"])

@@ -41,13 +41,34 @@ __global__ void __launch_bounds__(256, (NT <= 13 ? 2 : 1))
     const uint16_t *base = qkv + (size_t)b * T * ld + head * 64;
 
     // ---- stage K and V rows (16-byte chunks, swizzled; rows past T are zero) -------------------------------
-    for (int idx = tid; idx < (KROWS + VROWS) * 8; idx += 256) {
-        const bool is_v = idx >= KROWS * 8;
-        const int i2 = is_v ? idx - KROWS * 8 : idx;
-        const int key = i2 >> 3, c = i2 & 7;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (key < T) v = *reinterpret_cast<const uint4 *>(base + (size_t)key * ld + (is_v ? 2 * H : H) + c * 8);
-        *reinterpret_cast<uint4 *>((is_v ? vl : kl) + key * 128 + ((c ^ (key & 7)) << 4)) = v;
+    // loads are issued in batches of 7 before their LDS writes so that each thread keeps 7 x 16 B in flight
+    {
+        constexpr int TOTAL = (KROWS + VROWS) * 8;
+        constexpr int ITERS = (TOTAL + 255) / 256;
+        constexpr int BATCH = 7;
+#pragma unroll
+        for (int it0 = 0; it0 < ITERS; it0 += BATCH) {
+            uint4 v[BATCH];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int idx = tid + (it0 + u) * 256;
+                const bool is_v = idx >= KROWS * 8;
+                const int i2 = is_v ? idx - KROWS * 8 : idx;
+                const int key = i2 >> 3, c = i2 & 7;
+                v[u] = make_uint4(0, 0, 0, 0);
+                if (it0 + u < ITERS && idx < TOTAL && key < T)
+                    v[u] = *reinterpret_cast<const uint4 *>(base + (size_t)key * ld + (is_v ? 2 * H : H) + c * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int idx = tid + (it0 + u) * 256;
+                const bool is_v = idx >= KROWS * 8;
+                const int i2 = is_v ? idx - KROWS * 8 : idx;
+                const int key = i2 >> 3, c = i2 & 7;
+                if (it0 + u < ITERS && idx < TOTAL)
+                    *reinterpret_cast<uint4 *>((is_v ? vl : kl) + key * 128 + ((c ^ (key & 7)) << 4)) = v[u];
+            }
+        }
     }
     __syncthreads();
 
@@ -63,6 +84,7 @@ __global__ void __launch_bounds__(256, (NT <= 13 ? 2 : 1))
         const vec8 q0 = __builtin_bit_cast(vec8, *reinterpret_cast<const uint4 *>(qp + 8 * h));
         const vec8 q1 = __builtin_bit_cast(vec8, *reinterpret_cast<const uint4 *>(qp + 32 + 8 * h));
 
+        // raw scores; key tiles that reach past T get their tail masked (block-uniform test)
         f32x4 s[NT];
         float mx = -INFINITY;
 #pragma unroll
@@ -73,22 +95,23 @@ __global__ void __launch_bounds__(256, (NT <= 13 ? 2 : 1))
             f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
             a = E::mfma16(k0, q0, a);
             a = E::mfma16(k1, q1, a);
+            if (kt * 16 + 16 > T) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool kvalid = kt * 16 + 4 * h + j < T;
-                a[j] = kvalid ? a[j] * scale_log2e : -INFINITY;
-                mx = fmaxf(mx, a[j]);
+                for (int j = 0; j < 4; ++j) a[j] = (kt * 16 + 4 * h + j < T) ? a[j] : -INFINITY;
             }
+            mx = fmaxf(fmaxf(mx, fmaxf(a[0], a[1])), fmaxf(a[2], a[3]));
             s[kt] = a;
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        // exp((s - max) / 8) = exp2(s * c - max * c): one fma + one v_exp per score
+        const float neg_mxc = -mx * scale_log2e;
         float sum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float e = __builtin_amdgcn_exp2f(s[kt][j] - mx);
+                const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][j], scale_log2e, neg_mxc));
                 s[kt][j] = e;
                 sum += e;
             }

@@ -9,7 +9,7 @@
 #include "vm_kernels.h"
 
 // ---------------------------------------------------------------------------------------------------------
-// small HBM-bound kernels
+// HBM-bound kernels between the GEMMs
 // ---------------------------------------------------------------------------------------------------------
 namespace {
 
@@ -19,25 +19,51 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// One wave per row, H = 256 * VPL elements, lane owns float4 chunks lane + 64*i.  Two-pass statistics in
-// registers (mean, then mean of squared deviations), as the oracle computes them.
-template <int DT, int VPL, bool TO16>
-__global__ void __launch_bounds__(256) layernorm_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
-                                                        const float *__restrict__ beta, float eps,
-                                                        uint16_t *__restrict__ out16, float *__restrict__ out32,
-                                                        int rows, int H, int64_t row_stride) {
+template <int DT>
+__device__ __forceinline__ float4 load4_16(const uint16_t *p) {
+    using E = vm_elem<DT>;
+    const uint2 v = *reinterpret_cast<const uint2 *>(p);
+    const uint16_t *e = reinterpret_cast<const uint16_t *>(&v);
+    return make_float4(E::to_float(e[0]), E::to_float(e[1]), E::to_float(e[2]), E::to_float(e[3]));
+}
+
+// Residual add + LayerNorm, one wave per token row, H = 256 * VPL, lane owns 4-element chunks lane + 64*i.
+//   x_new = x32[row] + delta16[row]        (delta = the previous GEMM's 16-bit output; skipped when delta == null)
+//   x32[row] = x_new                       (fp32 residual stream stays in HBM / Infinity Cache)
+//   out16[row] = LN(x_new) * gamma + beta  (the next GEMM's A operand)
+// Two-pass statistics in registers (mean, then mean of squared deviations), as the oracle computes them.
+// The GEMMs therefore never read the residual: their epilogues are pure 16-bit stores.
+template <int DT, int VPL>
+__global__ void __launch_bounds__(256) resid_layernorm_kernel(float *__restrict__ x32,
+                                                              const uint16_t *__restrict__ delta16,
+                                                              const float *__restrict__ gamma,
+                                                              const float *__restrict__ beta, float eps,
+                                                              uint16_t *__restrict__ out16, int rows, int H) {
     using E = vm_elem<DT>;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const float4 *xr = reinterpret_cast<const float4 *>(x + (size_t)row * row_stride);
+    float4 *xr = reinterpret_cast<float4 *>(x32 + (size_t)row * H);
     float4 v[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) v[i] = xr[lane + 64 * i];
+    if (delta16) {
+        const uint16_t *dr = delta16 + (size_t)row * H;
+        float4 d[VPL];
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) d[i] = load4_16<DT>(dr + 4 * (lane + 64 * i));
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            v[i].x += d[i].x;
+            v[i].y += d[i].y;
+            v[i].z += d[i].z;
+            v[i].w += d[i].w;
+            xr[lane + 64 * i] = v[i];
+        }
+    }
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-        v[i] = xr[lane + 64 * i];
-        sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-    }
+    for (int i = 0; i < VPL; ++i) sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     const float mean = wave_sum(sum) / (float)H;
     float sq = 0.f;
 #pragma unroll
@@ -50,39 +76,78 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float *__restrict_
     for (int i = 0; i < VPL; ++i) {
         const float4 g4 = reinterpret_cast<const float4 *>(gamma)[lane + 64 * i];
         const float4 b4 = reinterpret_cast<const float4 *>(beta)[lane + 64 * i];
-        const float y0 = (v[i].x - mean) * rstd * g4.x + b4.x, y1 = (v[i].y - mean) * rstd * g4.y + b4.y;
-        const float y2 = (v[i].z - mean) * rstd * g4.z + b4.z, y3 = (v[i].w - mean) * rstd * g4.w + b4.w;
-        if (TO16) {
-            uint16_t o[4] = {E::from_float(y0), E::from_float(y1), E::from_float(y2), E::from_float(y3)};
-            uint2 pk;
-            __builtin_memcpy(&pk, o, 8);
-            reinterpret_cast<uint2 *>(out16 + (size_t)row * H)[lane + 64 * i] = pk;
-        } else {
-            reinterpret_cast<float4 *>(out32 + (size_t)row * row_stride)[lane + 64 * i] = make_float4(y0, y1, y2, y3);
-        }
+        uint16_t o[4] = {E::from_float((v[i].x - mean) * rstd * g4.x + b4.x),
+                         E::from_float((v[i].y - mean) * rstd * g4.y + b4.y),
+                         E::from_float((v[i].z - mean) * rstd * g4.z + b4.z),
+                         E::from_float((v[i].w - mean) * rstd * g4.w + b4.w)};
+        uint2 pk;
+        __builtin_memcpy(&pk, o, 8);
+        reinterpret_cast<uint2 *>(out16 + (size_t)row * H)[lane + 64 * i] = pk;
     }
 }
 
-__global__ void cls_rows_kernel(float *__restrict__ x, const float *__restrict__ cls, const float *__restrict__ pos,
-                                int T, int H) {
-    float *dst = x + (size_t)blockIdx.x * T * H;
-    for (int i = threadIdx.x; i < H; i += blockDim.x) dst[i] = cls[i] + pos[i];
+// Embedding assembly, one wave per token row: x32[frame*T + tok] = (tok ? patch16[frame*P + tok - 1] : cls) + pos[tok],
+// followed by the optional pre-LayerNorm of CLIP (fp32 in, fp32 out).
+template <int DT, int VPL>
+__global__ void __launch_bounds__(256) embed_kernel(const uint16_t *__restrict__ patch16, const float *__restrict__ cls,
+                                                    const float *__restrict__ pos, const float *__restrict__ pre_g,
+                                                    const float *__restrict__ pre_b, float eps, int pre_ln,
+                                                    float *__restrict__ x32, int rows, int T, int H) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int frame = row / T, tok = row - frame * T;
+    float4 v[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = lane + 64 * i;
+        const float4 p4 = reinterpret_cast<const float4 *>(pos + (size_t)tok * H)[c];
+        float4 e4;
+        if (tok == 0)
+            e4 = reinterpret_cast<const float4 *>(cls)[c];
+        else
+            e4 = load4_16<DT>(patch16 + ((size_t)frame * (T - 1) + tok - 1) * H + 4 * c);
+        v[i] = make_float4(e4.x + p4.x, e4.y + p4.y, e4.z + p4.z, e4.w + p4.w);
+    }
+    if (pre_ln) {
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        const float mean = wave_sum(sum) / (float)H;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            sq += (a * a + b * b) + (c * c + d * d);
+        }
+        const float rstd = rsqrtf(wave_sum(sq) / (float)H + eps);
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const float4 g4 = reinterpret_cast<const float4 *>(pre_g)[lane + 64 * i];
+            const float4 b4 = reinterpret_cast<const float4 *>(pre_b)[lane + 64 * i];
+            v[i] = make_float4((v[i].x - mean) * rstd * g4.x + b4.x, (v[i].y - mean) * rstd * g4.y + b4.y,
+                               (v[i].z - mean) * rstd * g4.z + b4.z, (v[i].w - mean) * rstd * g4.w + b4.w);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) reinterpret_cast<float4 *>(x32 + (size_t)row * H)[lane + 64 * i] = v[i];
 }
 
-// One block per frame: LayerNorm of the CLS row (fp32), optional projection W[proj_dim, H] (16-bit weights,
-// 16-bit rounded input, fp32 accumulate), optional L2 normalisation, cast to 16 bit.
+// One block per frame: CLS row = x32 + delta16 (the last FC2 output), final LayerNorm (fp32), optional projection
+// W[proj_dim, H] (16-bit weights, 16-bit rounded input, fp32 accumulate), optional L2 normalisation, cast to 16 bit.
 template <int DT>
-__global__ void __launch_bounds__(256) pool_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
-                                                   const float *__restrict__ beta, float eps,
-                                                   const uint16_t *__restrict__ proj_w, int proj_dim, int l2,
+__global__ void __launch_bounds__(256) pool_kernel(const float *__restrict__ x, const uint16_t *__restrict__ delta16,
+                                                   const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                   float eps, const uint16_t *__restrict__ proj_w, int proj_dim, int l2,
                                                    uint16_t *__restrict__ out, int T, int H) {
     using E = vm_elem<DT>;
-    extern __shared__ __attribute__((aligned(16))) float sh[];  // [H] normalised row, then [out_dim] result
+    extern __shared__ __attribute__((aligned(16))) float sh[];  // [H] row, then [out_dim] result
     __shared__ float red[8];
     float *y = sh;
     float *res = sh + H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float *row = x + (size_t)blockIdx.x * T * H;
+    const uint16_t *drow = delta16 + (size_t)blockIdx.x * T * H;
     auto block_sum = [&](float v) {
         v = wave_sum(v);
         __syncthreads();
@@ -91,15 +156,19 @@ __global__ void __launch_bounds__(256) pool_kernel(const float *__restrict__ x, 
         return (red[0] + red[1]) + (red[2] + red[3]);
     };
     float s = 0.f;
-    for (int i = tid; i < H; i += 256) s += row[i];
+    for (int i = tid; i < H; i += 256) {
+        const float v = row[i] + E::to_float(drow[i]);
+        y[i] = v;
+        s += v;
+    }
     const float mean = block_sum(s) / (float)H;
     float sq = 0.f;
     for (int i = tid; i < H; i += 256) {
-        const float d = row[i] - mean;
+        const float d = y[i] - mean;
         sq += d * d;
     }
     const float rstd = rsqrtf(block_sum(sq) / (float)H + eps);
-    for (int i = tid; i < H; i += 256) y[i] = (row[i] - mean) * rstd * gamma[i] + beta[i];
+    for (int i = tid; i < H; i += 256) y[i] = (y[i] - mean) * rstd * gamma[i] + beta[i];
     __syncthreads();
     int od = H;
     const float *src = y;
@@ -127,67 +196,60 @@ __global__ void __launch_bounds__(256) pool_kernel(const float *__restrict__ x, 
 
 }  // namespace
 
-int vm_layernorm16(vm_ctx *ctx, int dtype, const float *x, const float *gamma, const float *beta, float eps,
-                   uint16_t *out, int rows, int H, hipStream_t st) {
+#define VM_VPL_SWITCH(H, CALL)                                                                     \
+    switch ((H) / 256) {                                                                           \
+        case 1: CALL(1); break;                                                                    \
+        case 2: CALL(2); break;                                                                    \
+        case 3: CALL(3); break;                                                                    \
+        case 4: CALL(4); break;                                                                    \
+        default: return vm_fail(ctx, VM_ERR_UNSUPPORTED, "row width %d (need 256..1024, %%256)", H); \
+    }
+
+int vm_resid_layernorm(vm_ctx *ctx, int dtype, float *x32, const uint16_t *delta16, const float *gamma,
+                       const float *beta, float eps, uint16_t *out16, int rows, int H, hipStream_t st) {
     const int blocks = (rows + 3) / 4;
+    if (H % 256 != 0) return vm_fail(ctx, VM_ERR_UNSUPPORTED, "row width %d", H);
     vm_prof_scope prof(ctx, VM_PROF_LAYERNORM, st);
-#define LN(DTV, VPLV) layernorm_kernel<DTV, VPLV, true><<<blocks, 256, 0, st>>>(x, gamma, beta, eps, out, nullptr, rows, H, H)
-    if (H % 256 != 0 || H / 256 > 8) return vm_fail(ctx, VM_ERR_UNSUPPORTED, "layernorm width %d", H);
-    const int vpl = H / 256;
+#define RLN16(V) resid_layernorm_kernel<VM_F16, V><<<blocks, 256, 0, st>>>(x32, delta16, gamma, beta, eps, out16, rows, H)
+#define RLNB16(V) resid_layernorm_kernel<VM_BF16, V><<<blocks, 256, 0, st>>>(x32, delta16, gamma, beta, eps, out16, rows, H)
     if (dtype == VM_F16) {
-        switch (vpl) {
-            case 1: LN(VM_F16, 1); break;
-            case 2: LN(VM_F16, 2); break;
-            case 3: LN(VM_F16, 3); break;
-            case 4: LN(VM_F16, 4); break;
-            default: return vm_fail(ctx, VM_ERR_UNSUPPORTED, "layernorm width %d", H);
-        }
+        VM_VPL_SWITCH(H, RLN16)
     } else {
-        switch (vpl) {
-            case 1: LN(VM_BF16, 1); break;
-            case 2: LN(VM_BF16, 2); break;
-            case 3: LN(VM_BF16, 3); break;
-            case 4: LN(VM_BF16, 4); break;
-            default: return vm_fail(ctx, VM_ERR_UNSUPPORTED, "layernorm width %d", H);
-        }
+        VM_VPL_SWITCH(H, RLNB16)
     }
-#undef LN
+#undef RLN16
+#undef RLNB16
     VM_LAUNCH_CHECK(ctx);
     return VM_OK;
 }
 
-int vm_layernorm32_inplace(vm_ctx *ctx, float *x, const float *gamma, const float *beta, float eps, int rows, int H,
-                           hipStream_t st) {
-    const int blocks = (rows + 3) / 4;
+int vm_embed(vm_ctx *ctx, int dtype, const uint16_t *patch16, const float *cls, const float *pos, const float *pre_g,
+             const float *pre_b, float eps, int pre_ln, float *x32, int B, int T, int H, hipStream_t st) {
+    const int rows = B * T, blocks = (rows + 3) / 4;
+    if (H % 256 != 0) return vm_fail(ctx, VM_ERR_UNSUPPORTED, "row width %d", H);
     vm_prof_scope prof(ctx, VM_PROF_LAYERNORM, st);
-#define LN(VPLV) layernorm_kernel<VM_F16, VPLV, false><<<blocks, 256, 0, st>>>(x, gamma, beta, eps, nullptr, x, rows, H, H)
-    switch (H / 256) {
-        case 1: LN(1); break;
-        case 2: LN(2); break;
-        case 3: LN(3); break;
-        case 4: LN(4); break;
-        default: return vm_fail(ctx, VM_ERR_UNSUPPORTED, "layernorm width %d", H);
+#define EMB16(V) embed_kernel<VM_F16, V><<<blocks, 256, 0, st>>>(patch16, cls, pos, pre_g, pre_b, eps, pre_ln, x32, rows, T, H)
+#define EMBB16(V) embed_kernel<VM_BF16, V><<<blocks, 256, 0, st>>>(patch16, cls, pos, pre_g, pre_b, eps, pre_ln, x32, rows, T, H)
+    if (dtype == VM_F16) {
+        VM_VPL_SWITCH(H, EMB16)
+    } else {
+        VM_VPL_SWITCH(H, EMBB16)
     }
-#undef LN
+#undef EMB16
+#undef EMBB16
     VM_LAUNCH_CHECK(ctx);
     return VM_OK;
 }
 
-int vm_cls_rows(vm_ctx *ctx, float *x, const float *cls, const float *pos, int B, int T, int H, hipStream_t st) {
-    vm_prof_scope prof(ctx, VM_PROF_POOL, st);
-    cls_rows_kernel<<<B, 256, 0, st>>>(x, cls, pos, T, H);
-    VM_LAUNCH_CHECK(ctx);
-    return VM_OK;
-}
-
-int vm_pool(vm_ctx *ctx, int dtype, const float *x, const float *gamma, const float *beta, float eps,
-            const uint16_t *proj_w, int proj_dim, int l2, uint16_t *out, int B, int T, int H, hipStream_t st) {
+int vm_pool(vm_ctx *ctx, int dtype, const float *x, const uint16_t *delta16, const float *gamma, const float *beta,
+            float eps, const uint16_t *proj_w, int proj_dim, int l2, uint16_t *out, int B, int T, int H,
+            hipStream_t st) {
     const size_t lds = (size_t)(H + (proj_dim > 0 ? proj_dim : 0)) * 4;
     vm_prof_scope prof(ctx, VM_PROF_POOL, st);
     if (dtype == VM_F16)
-        pool_kernel<VM_F16><<<B, 256, lds, st>>>(x, gamma, beta, eps, proj_w, proj_dim, l2, out, T, H);
+        pool_kernel<VM_F16><<<B, 256, lds, st>>>(x, delta16, gamma, beta, eps, proj_w, proj_dim, l2, out, T, H);
     else
-        pool_kernel<VM_BF16><<<B, 256, lds, st>>>(x, gamma, beta, eps, proj_w, proj_dim, l2, out, T, H);
+        pool_kernel<VM_BF16><<<B, 256, lds, st>>>(x, delta16, gamma, beta, eps, proj_w, proj_dim, l2, out, T, H);
     VM_LAUNCH_CHECK(ctx);
     return VM_OK;
 }
@@ -347,8 +409,8 @@ static int micro_batch_of(const vm_encoder *e, int B) {
 }
 
 struct Ws {
-    float *x32;
-    uint16_t *a16, *qkv16, *mlp16;
+    float *x32;                            // fp32 residual stream [rows, H]
+    uint16_t *a16, *d16, *qkv16, *mlp16;   // LN out / attention ctx, residual-branch output, QKV, MLP hidden
     size_t bytes;
 };
 static Ws carve(const vm_encoder *e, int mb, void *base) {
@@ -362,6 +424,7 @@ static Ws carve(const vm_encoder *e, int mb, void *base) {
     };
     w.x32 = (float *)take(rows * H * 4);
     w.a16 = (uint16_t *)take(rows * H * 2);
+    w.d16 = (uint16_t *)take(rows * H * 2);
     w.qkv16 = (uint16_t *)take(rows * 3 * H * 2);
     w.mlp16 = (uint16_t *)take(rows * M * 2);
     w.bytes = off;
@@ -393,49 +456,33 @@ extern "C" int vm_encode(vm_encoder *e, const void *patches, int B, void *out_em
         const int nb = B - b0 < mb ? B - b0 : mb;
         const int rows = nb * T;
         GemmArgs g;
-        memset(&g, 0, sizeof(g));
-        // patch embedding: [nb*P, patch_k] x [H, patch_k]^T -> x32 rows 1.. of every frame (+bias +pos)
-        g.X = (const uint16_t *)patches + (size_t)b0 * P * e->patch_k;
-        g.W = e->patch_w;
-        g.bias = e->patch_b;
-        g.out32 = ws.x32;
-        g.pos = e->pos;
-        g.M = nb * P;
-        g.N = H;
-        g.K = e->patch_k;
-        g.ldx = e->patch_k;
-        g.ldo = H;
-        g.P = P;
-        g.T = T;
-        if ((rc = vm_gemm(ctx, dt, g, EPI_PATCH, st)) != VM_OK) return rc;
-        if ((rc = vm_cls_rows(ctx, ws.x32, e->cls, e->pos, nb, T, H, st)) != VM_OK) return rc;
-        if (d.pre_ln && (rc = vm_layernorm32_inplace(ctx, ws.x32, e->pre_g, e->pre_b, d.ln_eps, rows, H, st)) != VM_OK)
-            return rc;
+        auto gemm16 = [&](const uint16_t *X, int ldx, const uint16_t *W, const float *bias, uint16_t *out, int M, int N,
+                          int K, int epi, int cat) {
+            memset(&g, 0, sizeof(g));
+            g.X = X; g.W = W; g.bias = bias; g.out16 = out;
+            g.M = M; g.N = N; g.K = K; g.ldx = ldx; g.ldo = N; g.prof_cat = cat;
+            return vm_gemm(ctx, dt, g, epi, st);
+        };
+        // patch embedding: [nb*P, patch_k] x [H, patch_k]^T (+bias) -> 16-bit rows; then x32 = rows + pos (+cls) [+pre-LN]
+        if ((rc = gemm16((const uint16_t *)patches + (size_t)b0 * P * e->patch_k, e->patch_k, e->patch_w, e->patch_b,
+                         ws.d16, nb * P, H, e->patch_k, EPI_STORE16, VM_PROF_GEMM_PATCH)) != VM_OK) return rc;
+        if ((rc = vm_embed(ctx, dt, ws.d16, e->cls, e->pos, e->pre_g, e->pre_b, d.ln_eps, d.pre_ln, ws.x32, nb, T, H,
+                           st)) != VM_OK) return rc;
+        const uint16_t *delta = nullptr;  // 16-bit output of the previous residual branch, not yet added to x32
         for (int l = 0; l < d.layers; ++l) {
             const LayerW &w = e->layers[l];
-            if ((rc = vm_layernorm16(ctx, dt, ws.x32, w.ln1_g, w.ln1_b, d.ln_eps, ws.a16, rows, H, st)) != VM_OK) return rc;
-            memset(&g, 0, sizeof(g));
-            g.X = ws.a16; g.W = w.qkv_w; g.bias = w.qkv_b; g.out16 = ws.qkv16;
-            g.M = rows; g.N = 3 * H; g.K = H; g.ldx = H; g.ldo = 3 * H;
-            if ((rc = vm_gemm(ctx, dt, g, EPI_STORE16, st)) != VM_OK) return rc;
+            if ((rc = vm_resid_layernorm(ctx, dt, ws.x32, delta, w.ln1_g, w.ln1_b, d.ln_eps, ws.a16, rows, H, st)) != VM_OK) return rc;
+            if ((rc = gemm16(ws.a16, H, w.qkv_w, w.qkv_b, ws.qkv16, rows, 3 * H, H, EPI_STORE16, VM_PROF_GEMM_QKV)) != VM_OK) return rc;
             if ((rc = vm_attention(ctx, dt, ws.qkv16, ws.a16, nb, T, d.heads, st)) != VM_OK) return rc;
-            memset(&g, 0, sizeof(g));
-            g.X = ws.a16; g.W = w.proj_w; g.bias = w.proj_b; g.out32 = ws.x32;
-            g.M = rows; g.N = H; g.K = H; g.ldx = H; g.ldo = H;
-            if ((rc = vm_gemm(ctx, dt, g, EPI_RESID32, st)) != VM_OK) return rc;
-            if ((rc = vm_layernorm16(ctx, dt, ws.x32, w.ln2_g, w.ln2_b, d.ln_eps, ws.a16, rows, H, st)) != VM_OK) return rc;
-            memset(&g, 0, sizeof(g));
-            g.X = ws.a16; g.W = w.fc1_w; g.bias = w.fc1_b; g.out16 = ws.mlp16;
-            g.M = rows; g.N = d.mlp; g.K = H; g.ldx = H; g.ldo = d.mlp;
-            if ((rc = vm_gemm(ctx, dt, g, act_epi, st)) != VM_OK) return rc;
-            memset(&g, 0, sizeof(g));
-            g.X = ws.mlp16; g.W = w.fc2_w; g.bias = w.fc2_b; g.out32 = ws.x32;
-            g.M = rows; g.N = H; g.K = d.mlp; g.ldx = d.mlp; g.ldo = H;
-            if ((rc = vm_gemm(ctx, dt, g, EPI_RESID32, st)) != VM_OK) return rc;
+            if ((rc = gemm16(ws.a16, H, w.proj_w, w.proj_b, ws.d16, rows, H, H, EPI_STORE16, VM_PROF_GEMM_RESID)) != VM_OK) return rc;
+            if ((rc = vm_resid_layernorm(ctx, dt, ws.x32, ws.d16, w.ln2_g, w.ln2_b, d.ln_eps, ws.a16, rows, H, st)) != VM_OK) return rc;
+            if ((rc = gemm16(ws.a16, H, w.fc1_w, w.fc1_b, ws.mlp16, rows, d.mlp, H, act_epi, VM_PROF_GEMM_ACT)) != VM_OK) return rc;
+            if ((rc = gemm16(ws.mlp16, d.mlp, w.fc2_w, w.fc2_b, ws.d16, rows, H, d.mlp, EPI_STORE16, VM_PROF_GEMM_RESID)) != VM_OK) return rc;
+            delta = ws.d16;
         }
         uint16_t *dst = (uint16_t *)out_emb + (size_t)b0 * e->out_dim;
-        if ((rc = vm_pool(ctx, dt, ws.x32, e->ln_g, e->ln_b, d.ln_eps, e->proj_w, d.proj_dim, l2_normalise, dst, nb, T,
-                          H, st)) != VM_OK)
+        if ((rc = vm_pool(ctx, dt, ws.x32, delta, e->ln_g, e->ln_b, d.ln_eps, e->proj_w, d.proj_dim, l2_normalise, dst,
+                          nb, T, H, st)) != VM_OK)
             return rc;
     }
     return VM_OK;

@@ -27,7 +27,26 @@ constexpr int HALF_BYTES = 128 * BK * 2;  // 128 rows x 64 k, 16 KiB
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *gbl_ptr_t;
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf-GELU with erfc(z) = (1 + a1 z + ... + a6 z^6)^-16 (Abramowitz & Stegun 7.1.28, |error| <= 3e-7 for z >= 0):
+// ~16 VALU instead of libm erff's ~40, far below the 16-bit output's rounding.  Negative inputs use erfc directly,
+// so the tail keeps its relative accuracy.
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    float p = 0.0000430638f;
+    p = __builtin_fmaf(p, z, 0.0002765672f);
+    p = __builtin_fmaf(p, z, 0.0001520143f);
+    p = __builtin_fmaf(p, z, 0.0092705272f);
+    p = __builtin_fmaf(p, z, 0.0422820123f);
+    p = __builtin_fmaf(p, z, 0.0705230784f);
+    p = __builtin_fmaf(p, z, 1.0f);
+    p = p * p;
+    p = p * p;
+    p = p * p;
+    p = p * p;
+    const float erfc_z = __builtin_amdgcn_rcpf(p);  // 0 when p overflows
+    const float half_x_erfc = 0.5f * x * erfc_z;
+    return x < 0.f ? half_x_erfc : x - half_x_erfc;
+}
 __device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
 
 // XCD-aware renumbering (bijective for any grid size): ids that share (blockIdx % 8) become neighbours.
@@ -265,8 +284,262 @@ __global__ void __launch_bounds__(512, 1) gemm256_kernel(GemmArgs g) {
         f32x4 col[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) col[i] = acc[i][j];
+        if (ABL & 8) {  // developer ablation: keep the accumulators live, skip the stores
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(col[i]));
+            continue;
+        }
         epilogue_row<DT, EPI, 8>(g, col, t, f0 + wr * 128 + 4 * h);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Persistent form of gemm256: one workgroup per CU walks tiles bid, bid+grid, ...  The K-tile stream continues across
+// tile boundaries: the first K-tile of the NEXT output tile is staged during the last K-tile of the current one, and
+// the epilogue's stores are left in flight (counted vmcnt) while the next tile's MFMAs start, so neither the
+// prologue latency nor the output write-back leaves the matrix pipe idle between tiles.
+// ---------------------------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int DT, int EPI>
+__global__ void __launch_bounds__(512, 1) gemm256p_kernel(GemmArgs g) {
+    using E = vm_elem<DT>;
+    using vec8 = typename E::vec8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // vector-memory operations an epilogue leaves behind the last LDS-DMA (its stores; loads are consumed before)
+    constexpr int EPI_STORES = (EPI == EPI_STORE16 || EPI == EPI_GELU16 || EPI == EPI_QGELU16) ? 16 : 32;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, h = lane >> 4;
+    const int tiles_n = g.N >> 8;
+    const int ntiles = ((g.M + 255) >> 8) * tiles_n;
+    const int vbid = xcd_remap(blockIdx.x, gridDim.x);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int K = g.K, M = g.M;
+    const int nk = K / BK;
+
+    const int srow = lane >> 3, scp = lane & 7;
+    const int chunk = scp ^ srow;
+    int wrow[2], xrow[2], lds_wa0[2], lds_xb0[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int q = 2 * wave + u;
+        const int wrow0 = (q < 8 ? q * 8 : 128 + (q - 8) * 8);
+        const int xrow0 = (q >> 2) * 64 + (q & 3) * 8;
+        wrow[u] = wrow0 + srow;
+        xrow[u] = xrow0 + srow;
+        lds_wa0[u] = wrow0 * 128;
+        lds_xb0[u] = 2 * HALF_BYTES + xrow0 * 128;
+    }
+    const uint16_t *src_wa0[2], *src_wa1[2], *src_xb0[2], *src_xb1[2];
+    auto set_sources = [&](int tile) {
+        const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+        const int t0 = tm << 8, f0 = tn << 8;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            src_wa0[u] = g.W + (size_t)(f0 + wrow[u]) * K + chunk * 8;
+            src_wa1[u] = src_wa0[u] + (size_t)64 * K;
+            int t_b0 = t0 + xrow[u], t_b1 = t0 + xrow[u] + 32;
+            if (t_b0 > M - 1) t_b0 = M - 1;
+            if (t_b1 > M - 1) t_b1 = M - 1;
+            src_xb0[u] = g.X + (size_t)t_b0 * g.ldx + chunk * 8;
+            src_xb1[u] = g.X + (size_t)t_b1 * g.ldx + chunk * 8;
+        }
+    };
+    auto dma2 = [&](const uint16_t *const (&src)[2], const int (&dst)[2], int extra, int kt, int buf) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[u] + kt * BK),
+                                             (lds_ptr_t)(smem + buf * 4 * HALF_BYTES + dst[u] + extra), 16, 0, 0);
+    };
+    auto stage_Wa0 = [&](int kt, int buf) { dma2(src_wa0, lds_wa0, 0, kt, buf); };
+    auto stage_Wa1 = [&](int kt, int buf) { dma2(src_wa1, lds_wa0, 64 * 128, kt, buf); };
+    auto stage_Xb0 = [&](int kt, int buf) { dma2(src_xb0, lds_xb0, 0, kt, buf); };
+    auto stage_Xb1 = [&](int kt, int buf) { dma2(src_xb1, lds_xb0, 32 * 128, kt, buf); };
+
+    const int sw0 = ((h ^ (r16 & 7)) << 4), sw1 = (((h + 4) ^ (r16 & 7)) << 4);
+    const int a_base = (wr * 128 + r16) * 128;
+    const int b_base = 2 * HALF_BYTES + (wc * 64 + r16) * 128;
+
+    f32x4 acc[8][4];
+    vec8 af[4][2], bf[4][2];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto read_a = [&](const char *buf, int half) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const char *p = buf + a_base + (half * 4 + i) * 2048;
+            af[i][0] = *reinterpret_cast<const vec8 *>(p + sw0);
+            af[i][1] = *reinterpret_cast<const vec8 *>(p + sw1);
+        }
+    };
+    auto read_b = [&](const char *buf, int half) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const char *p = buf + b_base + (half * 2 + j) * 2048;
+            bf[half * 2 + j][0] = *reinterpret_cast<const vec8 *>(p + sw0);
+            bf[half * 2 + j][1] = *reinterpret_cast<const vec8 *>(p + sw1);
+        }
+    };
+    auto mma = [&](int ahalf, int bhalf) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[ahalf * 4 + i][bhalf * 2 + j] =
+                        E::mfma16(af[i][s], bf[bhalf * 2 + j][s], acc[ahalf * 4 + i][bhalf * 2 + j]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+#define VM_BAR() __builtin_amdgcn_s_barrier()
+#define VM_LGKM0()                                         \
+    do {                                                   \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        __builtin_amdgcn_sched_barrier(0);                 \
+    } while (0)
+
+    int tile = vbid;
+    if (tile >= ntiles) return;  // whole workgroup leaves together (grid <= ntiles, so this never splits a barrier)
+    set_sources(tile);
+    stage_Wa0(0, 0);
+    stage_Xb0(0, 0);
+    stage_Xb1(0, 0);
+    stage_Wa1(0, 0);
+    wait_vmcnt<0>();
+    VM_BAR();
+    if (wr == 1) VM_BAR();  // wave row 1 runs one barrier behind wave row 0
+    zero_acc();
+
+    int gk = 0;            // K-tiles consumed so far (selects the LDS buffer)
+    bool after_epi = false;  // this wave has an epilogue's stores behind the LDS-DMA still in flight
+    while (true) {
+        const int next_tile = tile + gridDim.x;
+        const bool has_next = next_tile < ntiles;
+        for (int kt = 0; kt < nk; ++kt, ++gk) {
+            const char *buf = smem + (gk & 1) * 4 * HALF_BYTES;
+            const int nb = (gk + 1) & 1;
+            int skt = kt + 1;
+            bool more = skt < nk;
+            if (!more && has_next) {  // roll over to the next output tile's first K-tile
+                set_sources(next_tile);
+                skt = 0;
+                more = true;
+            }
+            // phase 1
+            read_a(buf, 0);
+            read_b(buf, 0);
+            if (more) {
+                stage_Wa0(skt, nb);
+                if (after_epi) wait_vmcnt<4 + EPI_STORES>(); else wait_vmcnt<4>();
+            } else {
+                if (after_epi) wait_vmcnt<EPI_STORES>(); else wait_vmcnt<0>();
+            }
+            VM_BAR();
+            VM_LGKM0();
+            mma(0, 0);
+            VM_BAR();
+            // phase 2
+            read_b(buf, 1);
+            if (more) {
+                stage_Xb0(skt, nb);
+                if (after_epi) wait_vmcnt<4 + EPI_STORES>(); else wait_vmcnt<4>();
+            } else if (after_epi) {
+                wait_vmcnt<EPI_STORES>();
+            }
+            VM_BAR();
+            VM_LGKM0();
+            mma(0, 1);
+            VM_BAR();
+            // phase 3
+            read_a(buf, 1);
+            if (more) stage_Xb1(skt, nb);
+            VM_BAR();
+            VM_LGKM0();
+            mma(1, 1);
+            VM_BAR();
+            // phase 4: retiring Wa0/Xb0 of the staged K-tile also retires every older store
+            if (more) {
+                stage_Wa1(skt, nb);
+                wait_vmcnt<4>();
+            }
+            after_epi = false;
+            VM_BAR();
+            mma(1, 0);
+            VM_BAR();
+        }
+        // epilogue.  acc[i][j][e] = out[token t0 + wc*64 + 16j + r16][feature f0 + wr*128 + 16i + 4h + e].
+        // 16-bit outputs go through a wave-private LDS transpose (the X region of the buffer just consumed: free
+        // until phase 2 of the next K-tile, and the two wave rows run their epilogues one barrier apart) so that
+        // every store instruction writes 4 rows x 256 contiguous bytes instead of 16 rows x 32 bytes.
+        {
+            const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+            const int t0 = tm << 8, f0 = tn << 8;
+            if (EPI == EPI_STORE16 || EPI == EPI_GELU16 || EPI == EPI_QGELU16) {
+                char *scratch = smem + ((gk - 1) & 1) * 4 * HALF_BYTES + 2 * HALF_BYTES + wc * 8192;
+                const int fw = f0 + wr * 128;
+                float4 b4[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) b4[i] = *reinterpret_cast<const float4 *>(g.bias + fw + 16 * i + 4 * h);
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const int row = 16 * jj + r16;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const f32x4 a = acc[i][2 * p + jj];
+                            float v[4] = {a[0] + b4[i].x, a[1] + b4[i].y, a[2] + b4[i].z, a[3] + b4[i].w};
+                            uint16_t o[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float y = v[e];
+                                if (EPI == EPI_GELU16) y = gelu_erf(y);
+                                if (EPI == EPI_QGELU16) y = quick_gelu(y);
+                                o[e] = E::from_float(y);
+                            }
+                            uint2 pk;
+                            __builtin_memcpy(&pk, o, 8);
+                            const int col_b = (32 * i + 8 * h) ^ ((row & 7) << 4);  // byte offset in the 256-B row
+                            *reinterpret_cast<uint2 *>(scratch + row * 256 + col_b) = pk;
+                        }
+                    }
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) {
+                        const int c = it * 64 + lane, row = c >> 4, ch = c & 15;
+                        const uint4 v = *reinterpret_cast<const uint4 *>(scratch + row * 256 + ((ch ^ (row & 7)) << 4));
+                        const int t = t0 + wc * 64 + 32 * p + row;
+                        if (t < M) *reinterpret_cast<uint4 *>(g.out16 + (size_t)t * g.ldo + fw + ch * 8) = v;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int t = t0 + wc * 64 + j * 16 + r16;
+                    f32x4 col[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) col[i] = acc[i][j];
+                    if (t < M) epilogue_row<DT, EPI, 8>(g, col, t, f0 + wr * 128 + 4 * h);
+                }
+            }
+        }
+        if (!has_next) break;
+        zero_acc();
+        tile = next_tile;
+        after_epi = true;
+    }
+    if (wr == 0) VM_BAR();  // match wave row 1's extra barrier
+#undef VM_BAR
+#undef VM_LGKM0
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -353,7 +626,7 @@ __global__ void __launch_bounds__(256, 2) gemm128_kernel(GemmArgs g) {
     }
 }
 
-int g_variant = 0;  // 0 auto, 1 force 128^2, 2 force 256^2 (tools/gemm_bench, VIDMEM_GEMM)
+int g_variant = 0;  // 0 auto, 1 force 128^2, 2 force 256^2 one tile per block, 3 force 256^2 persistent (tools/gemm_bench, VIDMEM_GEMM)
 
 template <int DT, int EPI>
 int launch_epi(vm_ctx *ctx, const GemmArgs &g, hipStream_t st) {
@@ -366,7 +639,7 @@ int launch_epi(vm_ctx *ctx, const GemmArgs &g, hipStream_t st) {
     const int tiles256 = ((g.M + 255) / 256) * (g.N / 256);
     const bool big_ok = g.N % 256 == 0;
     // a 256^2 grid must give (nearly) every CU a tile; below that the 128^2 kernel fills the chip better
-    const bool use256 = variant == 2 ? big_ok : (variant == 1 ? false : (big_ok && tiles256 * 10 >= ctx->num_cus * 8));
+    const bool use256 = (variant == 2 || variant == 3) ? big_ok : (variant == 1 ? false : (big_ok && tiles256 * 10 >= ctx->num_cus * 8));
 #ifdef VM_GEMM_ABLATE
     if (variant >= 16 && EPI == EPI_STORE16 && DT == VM_F16) {
         const size_t lds = 8 * HALF_BYTES;
@@ -377,13 +650,23 @@ int launch_epi(vm_ctx *ctx, const GemmArgs &g, hipStream_t st) {
         (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
         k<<<tiles256, 512, lds, st>>>(g);                                                                         \
     } break;
-        switch (abl) { ABLGO(1) ABLGO(2) ABLGO(3) ABLGO(4) ABLGO(5) ABLGO(6) ABLGO(7) default: break; }
+        switch (abl) { ABLGO(1) ABLGO(2) ABLGO(3) ABLGO(4) ABLGO(5) ABLGO(6) ABLGO(7) ABLGO(8) default: break; }
 #undef ABLGO
         VM_LAUNCH_CHECK(ctx);
         return VM_OK;
     }
 #endif
-    if (use256) {
+    if (use256 && variant != 2) {
+        auto kern = gemm256p_kernel<DT, EPI>;
+        static bool attr_set_p = false;
+        const size_t lds = 8 * HALF_BYTES;
+        if (!attr_set_p) {
+            VM_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set_p = true;
+        }
+        const int grid = tiles256 < ctx->num_cus ? tiles256 : ctx->num_cus;
+        kern<<<grid, 512, lds, st>>>(g);
+    } else if (use256) {
         auto kern = gemm256_kernel<DT, EPI>;
         static bool attr_set = false;
         const size_t lds = 8 * HALF_BYTES;
@@ -408,10 +691,7 @@ int launch_epi(vm_ctx *ctx, const GemmArgs &g, hipStream_t st) {
 
 template <int DT>
 int launch(vm_ctx *ctx, const GemmArgs &g, int epi, hipStream_t st) {
-    const int cat = epi == EPI_PATCH ? VM_PROF_GEMM_PATCH
-                    : epi == EPI_STORE16 ? VM_PROF_GEMM_QKV
-                    : epi == EPI_RESID32 ? VM_PROF_GEMM_RESID : VM_PROF_GEMM_ACT;
-    vm_prof_scope prof(ctx, cat, st);
+    vm_prof_scope prof(ctx, g.prof_cat, st);
     switch (epi) {
         case EPI_STORE16: return launch_epi<DT, EPI_STORE16>(ctx, g, st);
         case EPI_GELU16: return launch_epi<DT, EPI_GELU16>(ctx, g, st);

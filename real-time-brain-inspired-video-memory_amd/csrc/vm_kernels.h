@@ -20,6 +20,7 @@ struct GemmArgs {
     int M, N, K;
     int ldx, ldo;
     int P, T;           // EPI_PATCH only: patches per frame, tokens per frame
+    int prof_cat;       // vm_prof_cat of this launch (bench.py's per-kernel breakdown)
 };
 
 int vm_gemm(vm_ctx *ctx, int dtype, const GemmArgs &g, int epi, hipStream_t st);
@@ -28,14 +29,13 @@ int vm_gemm(vm_ctx *ctx, int dtype, const GemmArgs &g, int epi, hipStream_t st);
 int vm_attention(vm_ctx *ctx, int dtype, const uint16_t *qkv, uint16_t *ctx_out, int B, int T, int heads,
                  hipStream_t st);
 
-// x [rows, H] fp32 -> out [rows, H] 16-bit, LayerNorm(gamma, beta, eps)
-int vm_layernorm16(vm_ctx *ctx, int dtype, const float *x, const float *gamma, const float *beta, float eps,
-                   uint16_t *out, int rows, int H, hipStream_t st);
-// in-place fp32 LayerNorm (CLIP pre-LN on the residual stream)
-int vm_layernorm32_inplace(vm_ctx *ctx, float *x, const float *gamma, const float *beta, float eps, int rows, int H,
-                           hipStream_t st);
-// x[frame*T + 0, :] = cls + pos[0]
-int vm_cls_rows(vm_ctx *ctx, float *x, const float *cls, const float *pos, int B, int T, int H, hipStream_t st);
-// final LayerNorm of the CLS row, optional projection, optional L2 normalisation, cast
-int vm_pool(vm_ctx *ctx, int dtype, const float *x, const float *gamma, const float *beta, float eps,
-            const uint16_t *proj_w, int proj_dim, int l2, uint16_t *out, int B, int T, int H, hipStream_t st);
+// x32[row] += delta16[row] (skipped when delta16 == null); out16[row] = LayerNorm(x32[row]) * gamma + beta
+int vm_resid_layernorm(vm_ctx *ctx, int dtype, float *x32, const uint16_t *delta16, const float *gamma,
+                       const float *beta, float eps, uint16_t *out16, int rows, int H, hipStream_t st);
+// x32[frame*T + tok] = (tok ? patch16[frame*(T-1) + tok-1] : cls) + pos[tok], then the optional pre-LayerNorm
+int vm_embed(vm_ctx *ctx, int dtype, const uint16_t *patch16, const float *cls, const float *pos, const float *pre_g,
+             const float *pre_b, float eps, int pre_ln, float *x32, int B, int T, int H, hipStream_t st);
+// CLS row (x32 + delta16) -> final LayerNorm, optional projection, optional L2 normalisation, cast
+int vm_pool(vm_ctx *ctx, int dtype, const float *x, const uint16_t *delta16, const float *gamma, const float *beta,
+            float eps, const uint16_t *proj_w, int proj_dim, int l2, uint16_t *out, int B, int T, int H,
+            hipStream_t st);
