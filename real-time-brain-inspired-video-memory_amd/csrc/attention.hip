@@ -21,7 +21,9 @@ namespace {
 typedef short s4v __attribute__((__vector_size__(4 * sizeof(short))));
 typedef __attribute__((address_space(3))) s4v *lds_s4v_ptr;
 
-template <int DT, int NT>  // NT = key tiles of 16 (13 for 197 tokens, 37 for 577)
+// NT = key tiles of 16 (13 for 197 tokens, 37 for 577).  EXACT: T > 16*(NT-1), so only the last tile has masked keys
+// and the mask is resolved at compile time for every other tile.
+template <int DT, int NT, bool EXACT>
 __global__ void __launch_bounds__(256, (NT <= 13 ? 2 : 1))
     attention_kernel(const uint16_t *__restrict__ qkv, uint16_t *__restrict__ ctx_out, int T, int heads) {
     using E = vm_elem<DT>;
@@ -95,7 +97,7 @@ __global__ void __launch_bounds__(256, (NT <= 13 ? 2 : 1))
             f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
             a = E::mfma16(k0, q0, a);
             a = E::mfma16(k1, q1, a);
-            if (kt * 16 + 16 > T) {
+            if (EXACT ? (kt == NT - 1) : (kt * 16 + 16 > T)) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) a[j] = (kt * 16 + 4 * h + j < T) ? a[j] : -INFINITY;
             }
@@ -162,11 +164,11 @@ __global__ void __launch_bounds__(256, (NT <= 13 ? 2 : 1))
     }
 }
 
-template <int DT, int NT>
+template <int DT, int NT, bool EXACT>
 int launch(vm_ctx *ctx, const uint16_t *qkv, uint16_t *out, int B, int T, int heads, hipStream_t st) {
     constexpr int NS = (NT + 1) / 2;
     const size_t lds = (size_t)NT * 16 * 128 + (size_t)NS * 32 * 128;
-    auto kern = attention_kernel<DT, NT>;
+    auto kern = attention_kernel<DT, NT, EXACT>;
     static bool attr_set = false;
     if (!attr_set) {
         VM_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -181,10 +183,12 @@ int launch(vm_ctx *ctx, const uint16_t *qkv, uint16_t *out, int B, int T, int he
 template <int DT>
 int dispatch(vm_ctx *ctx, const uint16_t *qkv, uint16_t *out, int B, int T, int heads, hipStream_t st) {
     const int nt = (T + 15) / 16;
-    if (nt <= 2) return launch<DT, 2>(ctx, qkv, out, B, T, heads, st);
-    if (nt <= 5) return launch<DT, 5>(ctx, qkv, out, B, T, heads, st);
-    if (nt <= 13) return launch<DT, 13>(ctx, qkv, out, B, T, heads, st);
-    if (nt <= 37) return launch<DT, 37>(ctx, qkv, out, B, T, heads, st);
+    if (nt == 13) return launch<DT, 13, true>(ctx, qkv, out, B, T, heads, st);   // ViT-B/16-224: 197 tokens
+    if (nt == 37) return launch<DT, 37, true>(ctx, qkv, out, B, T, heads, st);   // CLIP-L/14-336: 577 tokens
+    if (nt <= 2) return launch<DT, 2, false>(ctx, qkv, out, B, T, heads, st);
+    if (nt <= 5) return launch<DT, 5, false>(ctx, qkv, out, B, T, heads, st);
+    if (nt <= 13) return launch<DT, 13, false>(ctx, qkv, out, B, T, heads, st);
+    if (nt <= 37) return launch<DT, 37, false>(ctx, qkv, out, B, T, heads, st);
     return vm_fail(ctx, VM_ERR_UNSUPPORTED, "attention: %d tokens > 592", T);
 }
 

@@ -8,15 +8,29 @@
 #include "vm_internal.h"
 #include "vm_kernels.h"
 
+#include <type_traits>
+
 // ---------------------------------------------------------------------------------------------------------
 // HBM-bound kernels between the GEMMs
 // ---------------------------------------------------------------------------------------------------------
 namespace {
 
+// Wave-wide sum in 6 DPP adds + one readlane (no LDS round trips): quad swaps, half-row and row mirrors give every
+// lane its 16-lane row sum; row_bcast15 / row_bcast31 carry the row sums forward so lane 63 holds the total.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    auto dpp_add = [](float x, auto ctrl, auto row_mask) {
+        const int y = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value,
+                                                  decltype(row_mask)::value, 0xf, false);
+        return x + __builtin_bit_cast(float, y);
+    };
+    using std::integral_constant;
+    v = dpp_add(v, integral_constant<int, 0xB1>{}, integral_constant<int, 0xf>{});   // quad_perm [1,0,3,2]
+    v = dpp_add(v, integral_constant<int, 0x4E>{}, integral_constant<int, 0xf>{});   // quad_perm [2,3,0,1]
+    v = dpp_add(v, integral_constant<int, 0x141>{}, integral_constant<int, 0xf>{});  // row_half_mirror
+    v = dpp_add(v, integral_constant<int, 0x140>{}, integral_constant<int, 0xf>{});  // row_mirror
+    v = dpp_add(v, integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{});  // row_bcast15 -> rows 1, 3
+    v = dpp_add(v, integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{});  // row_bcast31 -> rows 2, 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 template <int DT>
@@ -33,7 +47,7 @@ __device__ __forceinline__ float4 load4_16(const uint16_t *p) {
 //   out16[row] = LN(x_new) * gamma + beta  (the next GEMM's A operand)
 // Two-pass statistics in registers (mean, then mean of squared deviations), as the oracle computes them.
 // The GEMMs therefore never read the residual: their epilogues are pure 16-bit stores.
-template <int DT, int VPL>
+template <int DT, int VPL, int RPW>  // RPW rows per wave: all loads of both rows are in flight before the first use
 __global__ void __launch_bounds__(256) resid_layernorm_kernel(float *__restrict__ x32,
                                                               const uint16_t *__restrict__ delta16,
                                                               const float *__restrict__ gamma,
@@ -41,48 +55,64 @@ __global__ void __launch_bounds__(256) resid_layernorm_kernel(float *__restrict_
                                                               uint16_t *__restrict__ out16, int rows, int H) {
     using E = vm_elem<DT>;
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    float4 *xr = reinterpret_cast<float4 *>(x32 + (size_t)row * H);
-    float4 v[VPL];
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+    if (row0 >= rows) return;
+    float4 v[RPW][VPL];
+    float4 d[RPW][VPL];
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) v[i] = xr[lane + 64 * i];
-    if (delta16) {
-        const uint16_t *dr = delta16 + (size_t)row * H;
-        float4 d[VPL];
+    for (int r = 0; r < RPW; ++r) {
+        const int row = row0 + r < rows ? row0 + r : rows - 1;
+        const float4 *xr = reinterpret_cast<const float4 *>(x32 + (size_t)row * H);
 #pragma unroll
-        for (int i = 0; i < VPL; ++i) d[i] = load4_16<DT>(dr + 4 * (lane + 64 * i));
+        for (int i = 0; i < VPL; ++i) v[r][i] = xr[lane + 64 * i];
+        if (delta16) {
+            const uint16_t *dr = delta16 + (size_t)row * H;
 #pragma unroll
-        for (int i = 0; i < VPL; ++i) {
-            v[i].x += d[i].x;
-            v[i].y += d[i].y;
-            v[i].z += d[i].z;
-            v[i].w += d[i].w;
-            xr[lane + 64 * i] = v[i];
+            for (int i = 0; i < VPL; ++i) d[r][i] = load4_16<DT>(dr + 4 * (lane + 64 * i));
         }
     }
-    float sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < VPL; ++i) sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-    const float mean = wave_sum(sum) / (float)H;
-    float sq = 0.f;
+    float4 g4[VPL], b4[VPL];
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
-        const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
-        sq += (a * a + b * b) + (c * c + d * d);
+        g4[i] = reinterpret_cast<const float4 *>(gamma)[lane + 64 * i];
+        b4[i] = reinterpret_cast<const float4 *>(beta)[lane + 64 * i];
     }
-    const float rstd = rsqrtf(wave_sum(sq) / (float)H + eps);
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-        const float4 g4 = reinterpret_cast<const float4 *>(gamma)[lane + 64 * i];
-        const float4 b4 = reinterpret_cast<const float4 *>(beta)[lane + 64 * i];
-        uint16_t o[4] = {E::from_float((v[i].x - mean) * rstd * g4.x + b4.x),
-                         E::from_float((v[i].y - mean) * rstd * g4.y + b4.y),
-                         E::from_float((v[i].z - mean) * rstd * g4.z + b4.z),
-                         E::from_float((v[i].w - mean) * rstd * g4.w + b4.w)};
-        uint2 pk;
-        __builtin_memcpy(&pk, o, 8);
-        reinterpret_cast<uint2 *>(out16 + (size_t)row * H)[lane + 64 * i] = pk;
+    for (int r = 0; r < RPW; ++r) {
+        const int row = row0 + r;
+        if (row >= rows) break;
+        if (delta16) {
+            float4 *xr = reinterpret_cast<float4 *>(x32 + (size_t)row * H);
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                v[r][i].x += d[r][i].x;
+                v[r][i].y += d[r][i].y;
+                v[r][i].z += d[r][i].z;
+                v[r][i].w += d[r][i].w;
+                xr[lane + 64 * i] = v[r][i];
+            }
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) sum += (v[r][i].x + v[r][i].y) + (v[r][i].z + v[r][i].w);
+        const float mean = wave_sum(sum) / (float)H;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const float a = v[r][i].x - mean, b = v[r][i].y - mean, c = v[r][i].z - mean, e = v[r][i].w - mean;
+            sq += (a * a + b * b) + (c * c + e * e);
+        }
+        const float rstd = rsqrtf(wave_sum(sq) / (float)H + eps);
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            uint16_t o[4] = {E::from_float((v[r][i].x - mean) * rstd * g4[i].x + b4[i].x),
+                             E::from_float((v[r][i].y - mean) * rstd * g4[i].y + b4[i].y),
+                             E::from_float((v[r][i].z - mean) * rstd * g4[i].z + b4[i].z),
+                             E::from_float((v[r][i].w - mean) * rstd * g4[i].w + b4[i].w)};
+            uint2 pk;
+            __builtin_memcpy(&pk, o, 8);
+            reinterpret_cast<uint2 *>(out16 + (size_t)row * H)[lane + 64 * i] = pk;
+        }
     }
 }
 
@@ -207,11 +237,12 @@ __global__ void __launch_bounds__(256) pool_kernel(const float *__restrict__ x, 
 
 int vm_resid_layernorm(vm_ctx *ctx, int dtype, float *x32, const uint16_t *delta16, const float *gamma,
                        const float *beta, float eps, uint16_t *out16, int rows, int H, hipStream_t st) {
-    const int blocks = (rows + 3) / 4;
+    constexpr int RPW = 2;
+    const int blocks = (rows + 4 * RPW - 1) / (4 * RPW);
     if (H % 256 != 0) return vm_fail(ctx, VM_ERR_UNSUPPORTED, "row width %d", H);
     vm_prof_scope prof(ctx, VM_PROF_LAYERNORM, st);
-#define RLN16(V) resid_layernorm_kernel<VM_F16, V><<<blocks, 256, 0, st>>>(x32, delta16, gamma, beta, eps, out16, rows, H)
-#define RLNB16(V) resid_layernorm_kernel<VM_BF16, V><<<blocks, 256, 0, st>>>(x32, delta16, gamma, beta, eps, out16, rows, H)
+#define RLN16(V) resid_layernorm_kernel<VM_F16, V, RPW><<<blocks, 256, 0, st>>>(x32, delta16, gamma, beta, eps, out16, rows, H)
+#define RLNB16(V) resid_layernorm_kernel<VM_BF16, V, RPW><<<blocks, 256, 0, st>>>(x32, delta16, gamma, beta, eps, out16, rows, H)
     if (dtype == VM_F16) {
         VM_VPL_SWITCH(H, RLN16)
     } else {

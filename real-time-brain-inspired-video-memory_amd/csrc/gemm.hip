@@ -49,6 +49,36 @@ __device__ __forceinline__ float gelu_erf(float x) {
 }
 __device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
 
+// The same erf-GELU on two values at once: written on 2-vectors so that hipcc emits v_pk_fma_f32 / v_pk_mul_f32
+// (about 10 VALU per element).  The FC1 epilogue evaluates 65,536 of these per tile; scalar, it cost as much
+// vector-ALU time as the tile's whole MFMA loop.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
+    f32x2 ax;
+    ax.x = fabsf(x.x);
+    ax.y = fabsf(x.y);
+    const f32x2 z = ax * 0.70710678118654752f;
+    const f32x2 one = {1.0f, 1.0f};
+    f32x2 p = __builtin_elementwise_fma(z, f32x2{0.0000430638f, 0.0000430638f}, f32x2{0.0002765672f, 0.0002765672f});
+    p = __builtin_elementwise_fma(p, z, f32x2{0.0001520143f, 0.0001520143f});
+    p = __builtin_elementwise_fma(p, z, f32x2{0.0092705272f, 0.0092705272f});
+    p = __builtin_elementwise_fma(p, z, f32x2{0.0422820123f, 0.0422820123f});
+    p = __builtin_elementwise_fma(p, z, f32x2{0.0705230784f, 0.0705230784f});
+    p = __builtin_elementwise_fma(p, z, one);
+    p = p * p;
+    p = p * p;
+    p = p * p;
+    p = p * p;
+    f32x2 r;
+    r.x = __builtin_amdgcn_rcpf(p.x);
+    r.y = __builtin_amdgcn_rcpf(p.y);
+    const f32x2 hx = (x * 0.5f) * r;  // 0.5 x erfc(|x|/sqrt 2)
+    f32x2 o;
+    o.x = x.x < 0.f ? hx.x : x.x - hx.x;
+    o.y = x.y < 0.f ? hx.y : x.y - hx.y;
+    return o;
+}
+
 // XCD-aware renumbering (bijective for any grid size): ids that share (blockIdx % 8) become neighbours.
 __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
     const int xcd = orig & 7, qd = nwg >> 3, rm = nwg & 7;
@@ -304,7 +334,7 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int DT, int EPI>
+template <int DT, int EPI, int ABL = 0>  // ABL (developer ablation): 8 = no global stores, 16 = no epilogue at all
 __global__ void __launch_bounds__(512, 1) gemm256p_kernel(GemmArgs g) {
     using E = vm_elem<DT>;
     using vec8 = typename E::vec8;
@@ -410,6 +440,10 @@ __global__ void __launch_bounds__(512, 1) gemm256p_kernel(GemmArgs g) {
 
     int tile = vbid;
     if (tile >= ntiles) return;  // whole workgroup leaves together (grid <= ntiles, so this never splits a barrier)
+    // the whole bias vector sits in LDS behind the staging buffers: the epilogue then needs no vector-memory load
+    // (a load there would queue behind the LDS-DMA in flight and expose its full latency once per tile)
+    float *bias_lds = reinterpret_cast<float *>(smem + 8 * HALF_BYTES);
+    for (int i = tid; i < g.N; i += 512) bias_lds[i] = g.bias[i];
     set_sources(tile);
     stage_Wa0(0, 0);
     stage_Xb0(0, 0);
@@ -484,12 +518,17 @@ __global__ void __launch_bounds__(512, 1) gemm256p_kernel(GemmArgs g) {
         {
             const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
             const int t0 = tm << 8, f0 = tn << 8;
-            if (EPI == EPI_STORE16 || EPI == EPI_GELU16 || EPI == EPI_QGELU16) {
+            if (ABL & 16) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+            } else if (EPI == EPI_STORE16 || EPI == EPI_GELU16 || EPI == EPI_QGELU16) {
                 char *scratch = smem + ((gk - 1) & 1) * 4 * HALF_BYTES + 2 * HALF_BYTES + wc * 8192;
                 const int fw = f0 + wr * 128;
                 float4 b4[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) b4[i] = *reinterpret_cast<const float4 *>(g.bias + fw + 16 * i + 4 * h);
+                for (int i = 0; i < 8; ++i) b4[i] = *reinterpret_cast<const float4 *>(bias_lds + fw + 16 * i + 4 * h);
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
 #pragma unroll
@@ -498,15 +537,17 @@ __global__ void __launch_bounds__(512, 1) gemm256p_kernel(GemmArgs g) {
 #pragma unroll
                         for (int i = 0; i < 8; ++i) {
                             const f32x4 a = acc[i][2 * p + jj];
-                            float v[4] = {a[0] + b4[i].x, a[1] + b4[i].y, a[2] + b4[i].z, a[3] + b4[i].w};
-                            uint16_t o[4];
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                float y = v[e];
-                                if (EPI == EPI_GELU16) y = gelu_erf(y);
-                                if (EPI == EPI_QGELU16) y = quick_gelu(y);
-                                o[e] = E::from_float(y);
+                            f32x2 v01 = {a[0] + b4[i].x, a[1] + b4[i].y}, v23 = {a[2] + b4[i].z, a[3] + b4[i].w};
+                            if (EPI == EPI_GELU16) {
+                                v01 = gelu_erf2(v01);
+                                v23 = gelu_erf2(v23);
                             }
+                            if (EPI == EPI_QGELU16) {
+                                v01 = f32x2{quick_gelu(v01.x), quick_gelu(v01.y)};
+                                v23 = f32x2{quick_gelu(v23.x), quick_gelu(v23.y)};
+                            }
+                            const uint16_t o[4] = {E::from_float(v01.x), E::from_float(v01.y), E::from_float(v23.x),
+                                                   E::from_float(v23.y)};
                             uint2 pk;
                             __builtin_memcpy(&pk, o, 8);
                             const int col_b = (32 * i + 8 * h) ^ ((row & 7) << 4);  // byte offset in the 256-B row
@@ -518,7 +559,11 @@ __global__ void __launch_bounds__(512, 1) gemm256p_kernel(GemmArgs g) {
                         const int c = it * 64 + lane, row = c >> 4, ch = c & 15;
                         const uint4 v = *reinterpret_cast<const uint4 *>(scratch + row * 256 + ((ch ^ (row & 7)) << 4));
                         const int t = t0 + wc * 64 + 32 * p + row;
-                        if (t < M) *reinterpret_cast<uint4 *>(g.out16 + (size_t)t * g.ldo + fw + ch * 8) = v;
+                        if (ABL & 8) {
+                            asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+                        } else if (t < M) {
+                            *reinterpret_cast<uint4 *>(g.out16 + (size_t)t * g.ldo + fw + ch * 8) = v;
+                        }
                     }
                 }
             } else {
@@ -641,6 +686,21 @@ int launch_epi(vm_ctx *ctx, const GemmArgs &g, hipStream_t st) {
     // a 256^2 grid must give (nearly) every CU a tile; below that the 128^2 kernel fills the chip better
     const bool use256 = (variant == 2 || variant == 3) ? big_ok : (variant == 1 ? false : (big_ok && tiles256 * 10 >= ctx->num_cus * 8));
 #ifdef VM_GEMM_ABLATE
+    if (variant >= 1024 && DT == VM_F16) {  // persistent-kernel ablations: 1024 + 8 (no stores) / + 16 (no epilogue)
+        const size_t lds = 8 * HALF_BYTES + (size_t)g.N * 4;
+        const int grid = tiles256 < ctx->num_cus ? tiles256 : ctx->num_cus;
+        if (variant == 1024 + 8) {
+            auto k = gemm256p_kernel<VM_F16, EPI, 8>;
+            (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            k<<<grid, 512, lds, st>>>(g);
+        } else {
+            auto k = gemm256p_kernel<VM_F16, EPI, 16>;
+            (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            k<<<grid, 512, lds, st>>>(g);
+        }
+        VM_LAUNCH_CHECK(ctx);
+        return VM_OK;
+    }
     if (variant >= 16 && EPI == EPI_STORE16 && DT == VM_F16) {
         const size_t lds = 8 * HALF_BYTES;
         const int abl = variant >> 4;
@@ -659,9 +719,11 @@ int launch_epi(vm_ctx *ctx, const GemmArgs &g, hipStream_t st) {
     if (use256 && variant != 2) {
         auto kern = gemm256p_kernel<DT, EPI>;
         static bool attr_set_p = false;
-        const size_t lds = 8 * HALF_BYTES;
+        if (g.N > 8192) return vm_fail(ctx, VM_ERR_UNSUPPORTED, "gemm: N=%d > 8192", g.N);
+        const size_t lds = 8 * HALF_BYTES + (size_t)g.N * 4;  // staging + bias table
         if (!attr_set_p) {
-            VM_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            VM_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            8 * HALF_BYTES + 8192 * 4));
             attr_set_p = true;
         }
         const int grid = tiles256 < ctx->num_cus ? tiles256 : ctx->num_cus;

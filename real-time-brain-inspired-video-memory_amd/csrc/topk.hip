@@ -434,7 +434,11 @@ ScanPlan make_plan(const vm_memory *m, int Q, int k) {
     const int64_t ntiles = (m->cap + 15) / 16;
     int64_t want = (ntiles + nw - 1) / nw;
     const int per_cu = (p.cfg.QT * p.cfg.KL <= 32) ? 2 : 1;
-    int64_t lim = (int64_t)m->ctx->num_cus * per_cu;
+    // Row-blocks per query group.  One group (Q <= 64): as many as the chip holds, the scan is HBM-bound.  Many
+    // groups: the groups already fill the chip, and FEWER row-blocks per group means more rows per lane list, so
+    // the lists warm up and most scores fail the one-compare threshold test instead of paying a sorted insert.
+    int64_t lim = (int64_t)m->ctx->num_cus * per_cu / p.qgroups;
+    if (lim < 8) lim = 8;
     if (lim > MAX_BLOCKS) lim = MAX_BLOCKS;
     p.nblk = (int)(want < lim ? want : lim);
     if (p.nblk < 1) p.nblk = 1;

@@ -46,10 +46,12 @@ class ShardedRetriever:
                             device=queries.device)
         dist.all_gather_into_tensor(q_all, queries.contiguous(), group=self.group)
         s_loc, r_loc = self._local_topk(q_all, k, self.world, self.rank)
-        s_all = torch.empty((self.world,) + tuple(s_loc.shape), dtype=s_loc.dtype, device=s_loc.device)
-        r_all = torch.empty((self.world,) + tuple(r_loc.shape), dtype=r_loc.dtype, device=r_loc.device)
-        dist.all_gather_into_tensor(s_all, s_loc.contiguous(), group=self.group)
-        dist.all_gather_into_tensor(r_all, r_loc.contiguous(), group=self.group)
+        QA = s_loc.shape[0]
+        s_cat = torch.empty((self.world * QA, k), dtype=s_loc.dtype, device=s_loc.device)  # rank-major concatenation
+        r_cat = torch.empty((self.world * QA, k), dtype=r_loc.dtype, device=r_loc.device)
+        dist.all_gather_into_tensor(s_cat, s_loc.contiguous(), group=self.group)
+        dist.all_gather_into_tensor(r_cat, r_loc.contiguous(), group=self.group)
+        s_all, r_all = s_cat.view(self.world, QA, k), r_cat.view(self.world, QA, k)
         lo = self.rank * F
         return self._merge(s_all[:, lo:lo + F].contiguous(), r_all[:, lo:lo + F].contiguous())
 

@@ -1,0 +1,136 @@
+"""Drop-in replacements for the reference's similarity call sites, backed by EmbeddingMemory (HIP).
+
+Same names, argument meaning, return shapes and error convention as the reference:
+
+  * ``HipPreLLMSimilarity._calculate_batch_similarities(chunk_embeddings, neo4j_handler)``
+        <- PreLLMInjector._calculate_batch_similarities, src/components/pre_llm_injector.py:346-372
+        returns List[Q] of List[<=k] of (chunk_id, score); an Exception entry yields [] (:357-359);
+        k = embedder_config.top_k_chunk_with_batch_similarity.
+  * ``merge_batch_similarities``          <- the max-merge of src/components/pre_llm_injector.py:238-249
+        (host-side dict logic of the CALLER, kept as the reference has it).
+  * ``HipVectorSearch._vector_search_chunks(session, query)``
+        <- HybridRetriever._vector_search_chunks, src/pipeline/retriever_hybrid.py:284-323
+        returns List[{id,time,content,score,source:"vector"}]; any failure -> [] (:321-323).
+  * ``HipVectorSearch._post_compress_chunks(query, chunks)``
+        <- HybridRetriever._post_compress_chunks, src/pipeline/retriever_hybrid.py:465-514
+        keeps segments with cosine >= compression_threshold in encounter order, then [:top_k];
+        any failure -> chunks unchanged (:512-514).
+
+Hot-path helpers never raise (they log and degrade), exactly like the reference; programmer errors
+(shape / dtype, VidmemError VM_ERR_INVALID) do.
+"""
+from __future__ import annotations
+
+import logging
+from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from .memory import EmbeddingMemory
+
+logger = logging.getLogger("vidmem.similarity")
+
+
+def merge_batch_similarities(batch_similarities: Sequence[Sequence[Tuple[str, float]]],
+                             top_k_similar_batch: int) -> List[Tuple[str, float]]:
+    """src/components/pre_llm_injector.py:238-249: max score per chunk id (first-seen order), stable descending
+    sort, first ``top_k_similar_batch``."""
+    final_scores: Dict[str, float] = {}
+    for chunk_similarities in batch_similarities:
+        for chunk_id, score in chunk_similarities:
+            if chunk_id not in final_scores or score > final_scores[chunk_id]:
+                final_scores[chunk_id] = score
+    final_score_list = sorted(final_scores.items(), key=lambda x: x[1], reverse=True)
+    return final_score_list[:top_k_similar_batch]
+
+
+def batch_similarities(memory: EmbeddingMemory, chunk_embeddings: Sequence, top_k: int
+                       ) -> List[List[Tuple[str, float]]]:
+    """One batched top-k launch for every non-failed query; result re-threaded into the reference's list shape."""
+    ok_idx = [i for i, e in enumerate(chunk_embeddings) if not isinstance(e, Exception) and e is not None]
+    out: List[List[Tuple[str, float]]] = [[] for _ in chunk_embeddings]
+    if not ok_idx or memory.searchable == 0 or top_k <= 0:
+        return out
+    first = chunk_embeddings[ok_idx[0]]
+    if isinstance(first, torch.Tensor):
+        q = torch.stack([chunk_embeddings[i] for i in ok_idx])
+    else:
+        q = torch.tensor([list(chunk_embeddings[i]) for i in ok_idx], dtype=torch.float32)
+    scores, rows = memory.topk(q, top_k)
+    scores, rows = scores.cpu().tolist(), rows.cpu().tolist()
+    for slot, i in enumerate(ok_idx):
+        out[i] = [(memory.id_of(r), float(s)) for r, s in zip(rows[slot], scores[slot]) if r >= 0]
+    return out
+
+
+class HipPreLLMSimilarity:
+    """Mixin / stand-alone object for PreLLMInjector: set ``self.memory`` and ``self.embedder_config``."""
+
+    def __init__(self, memory: EmbeddingMemory, embedder_config: Any):
+        self.memory = memory
+        self.embedder_config = embedder_config
+
+    async def _calculate_batch_similarities(self, chunk_embeddings, neo4j_handler=None
+                                            ) -> List[List[Tuple[str, float]]]:
+        try:
+            return batch_similarities(self.memory, chunk_embeddings,
+                                      self.embedder_config.top_k_chunk_with_batch_similarity)
+        except _lib.VidmemError as e:
+            if e.code == _lib.VM_ERR_INVALID:
+                raise
+            logger.warning("similarity search failed: %s", e)  # reference: log and degrade to empty
+            return [[] for _ in chunk_embeddings]
+
+
+class HipVectorSearch:
+    """Mixin / stand-alone object for HybridRetriever's vector leg."""
+
+    def __init__(self, memory: EmbeddingMemory, embedder: Any, config: Any, min_score: float = 0.3,
+                 score_mode: int = _lib.VM_SCORE_RAW,
+                 splitter: Optional[Callable[[str], List[str]]] = None):
+        self.memory, self.embedder, self.config = memory, embedder, config
+        self.min_score, self.score_mode, self.splitter = min_score, score_mode, splitter
+
+    async def _vector_search_chunks(self, session, query) -> List[Dict[str, Any]]:
+        try:
+            query_embedding = await self.embedder.aembed_query(query)
+            scores, rows = self.memory.topk([query_embedding], self.config.top_k_chunks, min_score=self.min_score,
+                                            score_mode=self.score_mode)
+            chunks = []
+            for r, s in zip(rows[0].cpu().tolist(), scores[0].cpu().tolist()):
+                if r < 0:
+                    continue
+                meta = self.memory.meta[r] if r < len(self.memory.meta) and self.memory.meta[r] else {}
+                chunks.append({"id": self.memory.id_of(r), "time": meta.get("time"), "content": meta.get("content"),
+                               "score": float(s), "source": "vector"})
+            return chunks
+        except _lib.VidmemError as e:
+            if e.code == _lib.VM_ERR_INVALID:
+                raise
+            logger.warning("Vector search failed: %s", e)
+            return []
+        except Exception as e:  # embedder failure etc.: reference returns [] (retriever_hybrid.py:321-323)
+            logger.warning("Vector search failed: %s", e)
+            return []
+
+    async def _post_compress_chunks(self, query, chunks: List[Dict]) -> List[Dict]:
+        if not self.embedder or not chunks:
+            return chunks
+        try:
+            query_embedding = await self.embedder.aembed_query(query)
+            segments, owners = [], []
+            for chunk in chunks:
+                for segment in (self.splitter(chunk["content"]) if self.splitter else [chunk["content"]]):
+                    segments.append(segment)
+                    owners.append(chunk)
+            if not segments:
+                return []
+            seg_emb = [await self.embedder.aembed_query(s) for s in segments]
+            sims = self.memory.cosine_exact([query_embedding], seg_emb)[0].cpu().tolist()
+            kept = [{**owners[i], "content": segments[i], "compression_score": float(sims[i])}
+                    for i in range(len(segments)) if sims[i] >= self.config.compression_threshold]
+            return kept[: self.config.top_k]
+        except Exception as e:
+            logger.warning("Post-compression failed: %s", e)
+            return chunks

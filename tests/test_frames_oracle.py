@@ -1,0 +1,107 @@
+"""CPU: frame-side oracle (chunk plan restating src/pipeline/vlm_extractor.py:38-59,101-107; build-defined preprocess)
+and the host-side mirror of the same integers in vidmem.extractor."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import frames_ref as F
+
+# (fps, total_frames, chunk_size_seconds, frames_per_chunk) -> expected, worked by hand from the reference's lines
+TABLE = [
+    ((30.0, 900, 5.0, 5), dict(total_chunks=6, first=(0, 150, [0, 37, 74, 111, 149], "00:00-00:05"),
+                               last=(750, 900, [750, 787, 824, 861, 899], "00:25-00:30"))),
+    ((29.97, 1000, 5.0, 5), dict(total_chunks=6, first=(0, 149, [0, 37, 74, 111, 148], "00:00-00:04"),
+                                 last=(745, 894, [745, 782, 819, 856, 893], "00:24-00:29"))),
+    ((25.0, 60, 5.0, 16), dict(total_chunks=1, first=(0, 60, None, "00:00-00:02"), last=None)),  # max(1, int(60/125))
+    ((10.0, 35, 1.0, 16), dict(total_chunks=3, first=(0, 10, list(range(10)), "00:00-00:01"),
+                               last=(20, 30, list(range(20, 30)), "00:02-00:03"))),
+]
+
+
+@pytest.mark.parametrize("args,want", TABLE)
+def test_chunk_plan_matches_reference_arithmetic(args, want):
+    total, plan = F.chunk_plan_ref(*args)
+    assert total == want["total_chunks"] and len(plan) == total
+    s, e, idx, label = want["first"]
+    assert (plan[0]["start"], plan[0]["end"], plan[0]["time"]) == (s, e, label)
+    if idx is not None:
+        assert plan[0]["indices"] == idx
+    else:  # 60 frames < chunk of 125: one chunk of min(16, 60) picks over [0, 59]
+        assert plan[0]["indices"] == [int(i) for i in np.linspace(0, 59, 16, dtype=int)]
+    if want["last"]:
+        s, e, idx, label = want["last"]
+        assert (plan[-1]["start"], plan[-1]["end"], plan[-1]["indices"], plan[-1]["time"]) == (s, e, idx, label)
+    # host-side mirror used by FrameEmbeddingExtractor
+    from vidmem.extractor import chunk_plan
+    total2, plan2 = chunk_plan(*args)
+    assert total2 == total
+    assert [(p[0], p[1], p[2], p[3], p[4]) for p in plan2] == [
+        (p["chunk_idx"], p["start"], p["end"], p["indices"], p["time"]) for p in plan]
+
+
+def test_downscale_size():
+    assert F.downscale_720_size_ref(1080, 1920) == (720, 1280)
+    assert F.downscale_720_size_ref(720, 1280) == (720, 1280)
+    assert F.downscale_720_size_ref(2160, 3840) == (720, 1280)
+    assert F.downscale_720_size_ref(1081, 1921) == (720, int(1921 * (720 / 1081)))
+
+
+@pytest.mark.parametrize("hw", [(224, 224), (360, 640), (97, 131), (1080, 1920)])
+def test_preprocess_ref_equals_torch_bilinear(hw):
+    rng = np.random.default_rng(3)
+    frames = rng.integers(0, 256, size=(2, hw[0], hw[1], 3), dtype=np.uint8)
+    mean, std = (0.48145466, 0.4578275, 0.40821073), (0.26862954, 0.26130258, 0.27577711)
+    got = F.preprocess_ref(frames, 224, mean, std, layout="chw")
+    rgb = torch.from_numpy(frames[..., ::-1].copy()).permute(0, 3, 1, 2).float()
+    t = torch.nn.functional.interpolate(rgb, size=(224, 224), mode="bilinear", align_corners=False)
+    want = (t / 255.0 - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1)
+    assert np.abs(got - want.numpy()).max() < 5e-4  # same taps; fp32 rounding order differs (0.03 grey levels)
+
+
+def test_preprocess_ref_patch_layout_is_a_permutation():
+    rng = np.random.default_rng(4)
+    frames = rng.integers(0, 256, size=(1, 64, 64, 3), dtype=np.uint8)
+    chw = F.preprocess_ref(frames, 56, (0.5,) * 3, (0.5,) * 3, layout="chw")
+    pat = F.preprocess_ref(frames, 56, (0.5,) * 3, (0.5,) * 3, layout="patches", patch=14, k_pad=640)
+    assert pat.shape == (1, 16, 640) and (pat[..., 588:] == 0).all()
+    # patch (gy, gx), k = c*196 + py*14 + px
+    assert pat[0, 5, 2 * 196 + 3 * 14 + 7] == chw[0, 2, 1 * 14 + 3, 1 * 14 + 7]
+
+
+def test_extractor_sources_and_json_shape(tmp_path):
+    """Array source + JSON layout of FrameEmbeddingExtractor without touching the GPU (encoder/memory stubbed)."""
+    import asyncio
+    from types import SimpleNamespace
+    from vidmem import extractor as X
+
+    class FakeEnc:
+        device = torch.device("cpu")
+
+        def embed_frames(self, frames):
+            return torch.zeros((frames.shape[0], 8))
+
+    class FakeMem:
+        searchable = 0
+        def __init__(self): self.n = 0
+        def append(self, emb, ids=None, meta=None):
+            first = self.n; self.n += emb.shape[0]; return first
+        def id_of(self, r): return None
+
+    frames = np.zeros((35, 8, 8, 3), np.uint8)
+    p = tmp_path / "clip.npz"
+    np.savez(p, frames=frames, fps=np.float64(10.0))
+    cfg = SimpleNamespace(video=SimpleNamespace(chunk_size_seconds=1.0, frames_per_chunk=16))
+    ex = X.FrameEmbeddingExtractor(cfg, FakeEnc(), FakeMem(), top_k=3)
+    orig_sync = torch.cuda.synchronize
+    torch.cuda.synchronize = lambda *a, **k: None
+    try:
+        out = asyncio.run(ex.process_video(str(p), str(tmp_path / "out.json")))
+    finally:
+        torch.cuda.synchronize = orig_sync
+    d = json.load(open(out))
+    assert set(d) == {"metadata", "results"} and d["metadata"]["total_chunks"] == 3
+    assert [r["chunk_idx"] for r in d["results"]] == [0, 1, 2]
+    assert set(d["results"][0]) >= {"time", "content", "chunk_idx", "processing_time"}  # vlm_extractor.py:66-71
+    assert d["results"][2]["embedding_rows"] == list(range(20, 30)) and d["results"][1]["time"] == "00:01-00:02"

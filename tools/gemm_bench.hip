@@ -39,8 +39,8 @@ int main(int argc, char **argv) {
     GemmArgs g{}; g.prof_cat = VM_PROF_GEMM_QKV; g.X = (const uint16_t *)dx; g.W = (const uint16_t *)dw; g.bias = db; g.out16 = (uint16_t *)dout16; g.out32 = dout32;
     g.M = M; g.N = N; g.K = K; g.ldx = K; g.ldo = N;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    int vlist[] = {1, 2, 3, 2 + 128, 2 + 16, 2 + 32, 2 + 48, 2 + 64, 2 + 80, 2 + 112};
-    int nv = getenv("ABLATE") ? 10 : 3;
+    int vlist[] = {1, 2, 3, 1024 + 8, 1024 + 16, 2 + 128, 2 + 16, 2 + 32, 2 + 48, 2 + 64, 2 + 80, 2 + 112};
+    int nv = getenv("ABLATE") ? 5 : 3;
     for (int vi = 0; vi < nv; ++vi) {
         int variant = vlist[vi];
         if (variant >= 2 && N % 256) continue;
@@ -63,7 +63,7 @@ int main(int argc, char **argv) {
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
         printf("M=%d N=%d K=%d epi=%d variant=%s: %.1f us  %.0f TFLOP/s  maxerr %.3g (ref max %.3g) bad=%zu\n", M, N, K, epi,
-               variant == 1 ? "128^2" : (variant == 2 ? "256^2" : variant == 3 ? "256^2 persistent" : (variant == 130 ? "256 noSTORE" : variant == 18 ? "256 noDMA" : variant == 34 ? "256 noDSREAD" : variant == 50 ? "256 noDMA noDSREAD" : variant == 66 ? "256 noMFMA" : variant == 82 ? "256 noDMA noMFMA" : "256 none")), ms * 1e3, 2.0 * M * N * K / (ms * 1e-3) / 1e12, maxerr, maxref, bad);
+               variant == 1 ? "128^2" : (variant == 2 ? "256^2" : variant == 3 ? "256^2 persistent" : (variant == 1032 ? "256p noSTORE" : variant == 1040 ? "256p noEPILOGUE" : variant == 130 ? "256 noSTORE" : variant == 18 ? "256 noDMA" : variant == 34 ? "256 noDSREAD" : variant == 50 ? "256 noDMA noDSREAD" : variant == 66 ? "256 noMFMA" : variant == 82 ? "256 noDMA noMFMA" : "256 none")), ms * 1e3, 2.0 * M * N * K / (ms * 1e-3) / 1e12, maxerr, maxref, bad);
     }
     return 0;
 }
