@@ -155,6 +155,37 @@ class EmbeddingMemory:
                                               _lib.current_stream_ptr()))
         return out
 
+    # ---- persistence: the reference's only durable store is the `embedding` list property
+    # (src/components/neo4j_handler.py:229-242) and the export JSON (src/components/graph_exporter.py:61-67);
+    # here: raw 16-bit rows in row-id order + the host id / meta tables, one .npz ------------------------------
+    def snapshot(self, path: str) -> None:
+        import json
+        import numpy as np
+        total, n = len(self), self.searchable
+        phys = self.rows_tensor().view(torch.int16)
+        if self.ring and total > self.capacity:  # oldest row sits at slot total % capacity
+            head = total % self.capacity
+            phys = torch.cat([phys[head:], phys[:head]])
+        base = total - n
+        np.savez(path, rows=phys.cpu().numpy().view(np.uint16), dtype=self.dtype_name, dim=self.dim,
+                 first_row_id=base, graph_uuid=self.graph_uuid or "",
+                 ids=json.dumps(self.ids[base:total]), meta=json.dumps(self.meta[base:total]))
+
+    @classmethod
+    def restore(cls, path: str, capacity: Optional[int] = None, ring: bool = False, device: int = 0
+                ) -> "EmbeddingMemory":
+        """Row ids restart at 0 in the restored memory (ids / meta tables are restored in the same order)."""
+        import json
+        import numpy as np
+        z = np.load(path, allow_pickle=False)
+        rows = torch.from_numpy(z["rows"].view(np.int16))
+        dtype = str(z["dtype"])
+        mem = cls(capacity or max(rows.shape[0], 1), int(z["dim"]), dtype, ring=ring, device=device,
+                  graph_uuid=str(z["graph_uuid"]) or None)
+        if rows.shape[0]:
+            mem.append(rows.view(_torch_dtype(dtype)), ids=json.loads(str(z["ids"])), meta=json.loads(str(z["meta"])))
+        return mem
+
     def id_of(self, row: int) -> Optional[str]:
         return self.ids[row] if 0 <= row < len(self.ids) else None
 

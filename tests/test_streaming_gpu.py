@@ -1,0 +1,65 @@
+"""GPU: persistence round trip and the hipGraph-captured streaming loop (BASELINE config C5 shape, small)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cref
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(t):
+    return t.contiguous().view(torch.int16).cpu().numpy().view(np.uint16)
+
+
+def test_snapshot_restore_roundtrip(tmp_path):
+    from vidmem.memory import EmbeddingMemory
+    rng = np.random.default_rng(2)
+    rows = torch.tensor(rng.standard_normal((150, 256)), dtype=torch.float32).to(torch.float16)
+    mem = EmbeddingMemory(100, 256, "f16", ring=True, graph_uuid="g-1")
+    mem.append(rows[:90], ids=[f"u_{i}" for i in range(90)])
+    mem.append(rows[90:], ids=[f"u_{i}" for i in range(90, 150)])      # wraps: rows 50..149 survive
+    p = str(tmp_path / "mem.npz")
+    mem.snapshot(p)
+    back = EmbeddingMemory.restore(p)
+    assert len(back) == 100 and back.graph_uuid == "g-1" and back.ids[0] == "u_50" and back.ids[-1] == "u_149"
+    assert torch.equal(back.rows_tensor().cpu(), rows[50:])
+    q = rows[[60, 149]]
+    s1, r1 = mem.topk(q, 4)
+    s2, r2 = back.topk(q, 4)
+    assert torch.equal(s1, s2) and torch.equal(r1 - 50, r2)   # same answers, row ids rebased to 0
+
+
+def test_streaming_graph_matches_eager_and_oracle():
+    from vidmem import specs, synthetic as syn
+    from vidmem.encoder import FrameEncoder
+    from vidmem.memory import EmbeddingMemory
+    from vidmem.streaming import StreamingSession
+    spec = dict(specs.VIT_B16_224, layers=1)
+    w = syn.encoder_weights(spec, seed=5)
+    enc = FrameEncoder(spec, w, "f16")
+    B, cap, k = 16, 64, 5
+    mem = EmbeddingMemory(cap, 768, "f16", ring=True)
+    seed_rows = torch.from_numpy(syn.unit_rows(3, "seed", 40, 768)).to(torch.float16)
+    mem.append(seed_rows)
+    sess = StreamingSession(enc, mem, B, 360, 640, top_k=k, warmup=1)   # warmup + capture append B rows each
+    hist = [seed_rows.cuda()]
+    frames0 = torch.zeros((B, 360, 640, 3), dtype=torch.uint8, device="cuda")
+    e0 = enc.embed_frames(frames0)
+    hist += [e0, e0]                       # what warmup + capture pushed (frames_in was all zeros)
+    for step in range(4):                  # crosses the ring wrap
+        frames = torch.from_numpy(syn.frames_u8(100 + step, B, 360, 640)).cuda()
+        emb, scores, rows = sess.push(frames)
+        torch.cuda.synchronize()
+        want_emb = enc.embed_frames(frames)
+        assert torch.equal(emb, want_emb)
+        allrows = torch.cat(hist)
+        lo = max(0, allrows.shape[0] - cap)
+        want_r, want_s = cref.cosine_topk(_bits(emb), _bits(allrows[lo:]), k, dtype="f16")
+        want_r = np.where(want_r >= 0, want_r + lo, -1)
+        # zero frames give 32 identical rows: more ties than candidate slots can appear -> compare only certified
+        if int(mem._uncert.item()) == 0:
+            assert np.array_equal(rows.cpu().numpy(), want_r)
+            assert np.array_equal(scores.cpu().numpy(), want_s)
+        hist.append(emb.clone())
+    assert sess.rows_appended == 40 + 2 * B + 4 * B
