@@ -121,18 +121,22 @@ __global__ void __launch_bounds__(SCAN_THREADS)
         f32x4 acc[QT];
 #pragma unroll
         for (int t = 0; t < QT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int s0 = 0; s0 < ksteps; s0 += 4) {
-            uint4 a[4];
+        // LB independent 16-byte loads per lane are issued before their first use (8 KiB in flight per wave)
+        constexpr int LB = 8;
+        for (int s0 = 0; s0 < ksteps; s0 += LB) {
+            uint4 a[LB];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) a[u] = src[(s0 + u) * 4];
+            for (int u = 0; u < LB; ++u) a[u] = src[(s0 + u < ksteps ? s0 + u : ksteps - 1) * 4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int ci = h + 4 * (s0 + u);
-                const vec8 av = __builtin_bit_cast(vec8, a[u]);
+            for (int u = 0; u < LB; ++u) {
+                if (s0 + u < ksteps) {  // ksteps is a multiple of 4; uniform branch
+                    const int ci = h + 4 * (s0 + u);
+                    const vec8 av = __builtin_bit_cast(vec8, a[u]);
 #pragma unroll
-                for (int t = 0; t < QT; ++t) {
-                    const uint4 bq = qlds[(t * 16 + r16) * chunks + ((ci & ~15) | ((ci ^ r16) & 15))];
-                    acc[t] = E::mfma16(av, __builtin_bit_cast(vec8, bq), acc[t]);
+                    for (int t = 0; t < QT; ++t) {
+                        const uint4 bq = qlds[(t * 16 + r16) * chunks + ((ci & ~15) | ((ci ^ r16) & 15))];
+                        acc[t] = E::mfma16(av, __builtin_bit_cast(vec8, bq), acc[t]);
+                    }
                 }
             }
         }
@@ -249,7 +253,10 @@ __global__ void __launch_bounds__(FIN_THREADS)
     __shared__ int fo[KL];
     __shared__ double ex[KL];
     __shared__ double qnorm_sh;
+    __shared__ float qsq_sh[FIN_THREADS / 64];
     __shared__ int cnt, nqual;
+    extern __shared__ __attribute__((aligned(16))) char fin_dyn[];  // the query row, [D] 16-bit
+    uint16_t *ql = reinterpret_cast<uint16_t *>(fin_dyn);
 
     const int q = blockIdx.x, tid = threadIdx.x;
     const RingView rv = ring_view(*d_total, cap, ring);
@@ -257,6 +264,22 @@ __global__ void __launch_bounds__(FIN_THREADS)
     if (tid == 0) {
         cnt = 0;
         nqual = 0;
+    }
+    {   // stage the query row in LDS; fp32 upper bound of |q| (gates the any-order-exact fast paths below)
+        float sq = 0.f;
+        for (int i = tid; i < D / 8; i += FIN_THREADS) {
+            const uint4 v = reinterpret_cast<const uint4 *>(queries + (size_t)q * D)[i];
+            reinterpret_cast<uint4 *>(ql)[i] = v;
+            const uint16_t *e = reinterpret_cast<const uint16_t *>(&v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float x = E::to_float(e[j]);
+                sq += x * x;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+        if ((tid & 63) == 0) qsq_sh[tid >> 6] = sq;
     }
     for (int b = tid; b < nblk; b += FIN_THREADS) {
         hs[b] = part_s[((size_t)b * q_pad + q) * KL];
@@ -267,13 +290,61 @@ __global__ void __launch_bounds__(FIN_THREADS)
         fo[tid] = INT_MAX;
     }
     __syncthreads();
-    // lists whose head ranks among the KL best heads can contain members of the global top KL
-    for (int b = tid; b < nblk; b += FIN_THREADS) {
-        const float s = hs[b];
-        const int o = ho[b];
-        int rank = 0;
-        for (int d = 0; d < nblk; ++d) rank += (better(hs[d], ho[d], s, o) || (hs[d] == s && ho[d] == o && d < b));
-        if (rank < KL && s > -INFINITY) qual[atomicAdd(&nqual, 1)] = b;
+    // Lists whose head ranks among the KL best heads (score desc, order asc) can contain members of the global top
+    // KL.  One wave finds that cut with two bitwise binary searches held entirely in registers / SGPR ballots (the
+    // KL-th largest score key, then among equal scores the needed count of smallest orders): ~1.3k instructions
+    // instead of an O(lists^2) LDS rank count.
+    if (tid < 64) {
+        constexpr int HPL = MAX_BLOCKS / 64;
+        unsigned key[HPL];
+        int ord[HPL];
+#pragma unroll
+        for (int i = 0; i < HPL; ++i) {
+            const int b = tid + 64 * i;
+            const bool have = b < nblk && hs[b] > -INFINITY;
+            const unsigned u = __builtin_bit_cast(unsigned, have ? hs[b] : 0.f);
+            key[i] = have ? ((u & 0x80000000u) ? ~u : (u | 0x80000000u)) : 0u;  // order-preserving; 0 = no list
+            ord[i] = have ? ho[b] : INT_MAX;
+        }
+        auto count_ge = [&](unsigned cand) {
+            int c = 0;
+#pragma unroll
+            for (int i = 0; i < HPL; ++i) c += __popcll(__ballot(key[i] >= cand));
+            return c;
+        };
+        const int total = count_ge(1u);
+        const int want = total < KL ? total : KL;
+        unsigned tk = 0;  // largest key with count(key >= tk) >= want
+        if (want > 0) {
+            for (int bit = 31; bit >= 0; --bit) {
+                const unsigned cand = tk | (1u << bit);
+                if (count_ge(cand) >= want) tk = cand;
+            }
+        }
+        int n_gt = 0;
+#pragma unroll
+        for (int i = 0; i < HPL; ++i) n_gt += __popcll(__ballot(key[i] > tk));
+        const int need_eq = want - n_gt;  // >= 1 when want > 0
+        int to = 0;                        // smallest order with count(key == tk && ord <= to) >= need_eq
+        if (want > 0) {
+            auto count_eq_le = [&](int lim) {
+                int c = 0;
+#pragma unroll
+                for (int i = 0; i < HPL; ++i) c += __popcll(__ballot(key[i] == tk && ord[i] <= lim));
+                return c;
+            };
+            int lo = 0, hi = INT_MAX - 1;  // orders are distinct non-negative ints
+            while (lo < hi) {
+                const int mid = lo + (hi - lo) / 2;
+                if (count_eq_le(mid) >= need_eq) hi = mid; else lo = mid + 1;
+            }
+            to = lo;
+        }
+#pragma unroll
+        for (int i = 0; i < HPL; ++i) {
+            const bool take = want > 0 && key[i] != 0u && (key[i] > tk || (key[i] == tk && ord[i] <= to));
+            if (take) qual[atomicAdd(&nqual, 1)] = tid + 64 * i;
+        }
     }
     __syncthreads();
     const int nq_lists = nqual;
@@ -302,35 +373,86 @@ __global__ void __launch_bounds__(FIN_THREADS)
     __syncthreads();
     const int nfin = C < KL ? C : KL;
 
-    // exact re-scoring: thread t < nfin takes candidate t; thread KL takes the query norm.
-    const uint16_t *qv = queries + (size_t)q * D;
-    if (tid < nfin) {
-        int64_t p = fo[tid] + rv.head;
+    // exact re-scoring.  TPC = 256/KL threads share one candidate.
+    //  * fp16 rows with |q||m| < 32: fp16 x fp16 products are exact multiples of 2^-48 and every partial sum stays
+    //    below 32, so every partial sum is exactly representable in fp64: NO rounding occurs in ANY summation order,
+    //    and a parallel tree gives the reference's left-to-right result bit for bit (sum|q_i m_i| <= |q||m| bounds all
+    //    partial sums).  The TPC threads take interleaved 16-byte chunks and combine with shuffles.
+    //  * otherwise (bf16, or large norms): one thread sums strictly left to right, as the reference does.
+    // The query norm is handled the same way by the last wave's first TPC threads' neighbours (slot KL).
+    const uint16_t *qv = ql;  // LDS copy of the query row
+    const double qnorm_fast = 1.001 * sqrt((double)((qsq_sh[0] + qsq_sh[1]) + (qsq_sh[2] + qsq_sh[3])));
+    constexpr int TPC = FIN_THREADS / KL;  // 4 .. 32, a power of two dividing the wave
+    {
+        const int c = tid / TPC, sub = tid % TPC;
+        const bool live = c < nfin;
+        int64_t p = live ? fo[c] + rv.head : 0;
         if (p >= rv.cap) p -= rv.cap;
         const uint16_t *mv = mem + (size_t)p * D;
+        const bool any_order_exact = (DT == VM_F16) && live && (qnorm_fast * norm64[p] < 32.0);
         double dot = 0.0;
-        for (int i = 0; i < D; i += 8) {
-            const uint4 a = *reinterpret_cast<const uint4 *>(qv + i);
-            const uint4 b = *reinterpret_cast<const uint4 *>(mv + i);
-            const uint16_t *ae = reinterpret_cast<const uint16_t *>(&a);
-            const uint16_t *be = reinterpret_cast<const uint16_t *>(&b);
+        if (any_order_exact) {
+            double d0 = 0.0, d1 = 0.0;
+            for (int ch = sub; ch < D / 8; ch += TPC) {
+                const uint4 a = *reinterpret_cast<const uint4 *>(qv + ch * 8);
+                const uint4 b = *reinterpret_cast<const uint4 *>(mv + ch * 8);
+                const uint16_t *ae = reinterpret_cast<const uint16_t *>(&a);
+                const uint16_t *be = reinterpret_cast<const uint16_t *>(&b);
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                dot = __dadd_rn(dot, __dmul_rn(E::to_double(ae[j]), E::to_double(be[j])));
-        }
-        ex[tid] = dot;
-    } else if (tid == KL) {
-        double nq = 0.0;
-        for (int i = 0; i < D; i += 8) {
-            const uint4 a = *reinterpret_cast<const uint4 *>(qv + i);
-            const uint16_t *ae = reinterpret_cast<const uint16_t *>(&a);
+                for (int j = 0; j < 8; j += 2) {
+                    d0 = __dadd_rn(d0, __dmul_rn(E::to_double(ae[j]), E::to_double(be[j])));
+                    d1 = __dadd_rn(d1, __dmul_rn(E::to_double(ae[j + 1]), E::to_double(be[j + 1])));
+                }
+            }
+            dot = __dadd_rn(d0, d1);
+        } else if (live && sub == 0) {
+            for (int i = 0; i < D; i += 32) {  // D is a multiple of 128; 4 row chunks in flight per step
+                uint4 b4[4];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const double x = E::to_double(ae[j]);
-                nq = __dadd_rn(nq, __dmul_rn(x, x));
+                for (int u = 0; u < 4; ++u) b4[u] = *reinterpret_cast<const uint4 *>(mv + i + 8 * u);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint4 a = *reinterpret_cast<const uint4 *>(qv + i + 8 * u);
+                    const uint16_t *ae = reinterpret_cast<const uint16_t *>(&a);
+                    const uint16_t *be = reinterpret_cast<const uint16_t *>(&b4[u]);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        dot = __dadd_rn(dot, __dmul_rn(E::to_double(ae[j]), E::to_double(be[j])));
+                }
             }
         }
-        qnorm_sh = __dsqrt_rn(nq);
+#pragma unroll
+        for (int off = TPC / 2; off > 0; off >>= 1) dot = __dadd_rn(dot, __shfl_xor(dot, off, 64));  // zeros elsewhere
+        if (live && sub == 0) ex[c] = dot;
+    }
+    if (tid >= FIN_THREADS - 64) {  // last wave: the query norm (src/components/pre_llm_injector.py:382)
+        const int l = tid - (FIN_THREADS - 64);
+        const bool q_any_order = (DT == VM_F16) && (qnorm_fast * qnorm_fast < 32.0);  // wave-uniform
+        double nq = 0.0;
+        if (q_any_order) {  // squares of fp16 values: exact, and every partial sum < 32 -> order-free
+            for (int ch = l; ch < D / 8; ch += 64) {
+                const uint4 a = *reinterpret_cast<const uint4 *>(qv + ch * 8);
+                const uint16_t *ae = reinterpret_cast<const uint16_t *>(&a);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const double x = E::to_double(ae[j]);
+                    nq = __dadd_rn(nq, __dmul_rn(x, x));
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) nq = __dadd_rn(nq, __shfl_xor(nq, off, 64));
+        } else if (l == 0) {  // strictly left to right
+            for (int i = 0; i < D; i += 8) {
+                const uint4 a = *reinterpret_cast<const uint4 *>(qv + i);
+                const uint16_t *ae = reinterpret_cast<const uint16_t *>(&a);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const double x = E::to_double(ae[j]);
+                    nq = __dadd_rn(nq, __dmul_rn(x, x));
+                }
+            }
+        }
+        if (l == 0) qnorm_sh = __dsqrt_rn(nq);
     }
     __syncthreads();
     const double qn = qnorm_sh;
@@ -433,7 +555,12 @@ ScanPlan make_plan(const vm_memory *m, int Q, int k) {
     const int nw = SCAN_THREADS / 64;
     const int64_t ntiles = (m->cap + 15) / 16;
     int64_t want = (ntiles + nw - 1) / nw;
-    const int per_cu = (p.cfg.QT * p.cfg.KL <= 32) ? 2 : 1;
+    static int env_per_cu = -1;
+    if (env_per_cu < 0) {
+        const char *e = getenv("VIDMEM_TOPK_BLOCKS_PER_CU");
+        env_per_cu = e ? atoi(e) : 0;
+    }
+    const int per_cu = env_per_cu > 0 ? env_per_cu : ((p.cfg.QT * p.cfg.KL <= 32) ? 2 : 1);
     // Row-blocks per query group.  One group (Q <= 64): as many as the chip holds, the scan is HBM-bound.  Many
     // groups: the groups already fill the chip, and FEWER row-blocks per group means more rows per lane list, so
     // the lists warm up and most scores fail the one-compare threshold test instead of paying a sorted insert.
@@ -491,7 +618,7 @@ int run_topk(vm_memory *m, const ScanPlan &p, const void *queries, int Q, int k,
     if (rc != VM_OK) return rc;
     vm_prof_scope prof(m->ctx, VM_PROF_TOPK_FINALIZE, st);
 #define FIN(KLV)                                                                                           \
-    topk_finalize_kernel<DT, KLV><<<Q, FIN_THREADS, 0, st>>>(                                              \
+    topk_finalize_kernel<DT, KLV><<<Q, FIN_THREADS, (size_t)m->D * 2, st>>>(                                              \
         m->rows, m->norm64, (const uint16_t *)queries, m->d_total, m->cap, m->ring, m->D, p.q_pad, p.nblk, \
         part_s, part_o, k, use_min, min_score, score_mode, row_stride, row_offset, out_scores, out_rows,   \
         uncertified)
