@@ -511,10 +511,14 @@ __global__ void __launch_bounds__(512, 1) gemm256p_kernel(GemmArgs g) {
             mma(1, 0);
             VM_BAR();
         }
+        // Tile boundary: wave row 0 waits one barrier so that BOTH wave rows run their epilogues in the same interval
+        // (their LDS round trips and store issue overlap instead of serialising); wave row 1 takes its matching extra
+        // barrier after the epilogue, which also restores the one-barrier offset for the next tile.
+        if (wr == 0) VM_BAR();
         // epilogue.  acc[i][j][e] = out[token t0 + wc*64 + 16j + r16][feature f0 + wr*128 + 16i + 4h + e].
         // 16-bit outputs go through a wave-private LDS transpose (the X region of the buffer just consumed: free
-        // until phase 2 of the next K-tile, and the two wave rows run their epilogues one barrier apart) so that
-        // every store instruction writes 4 rows x 256 contiguous bytes instead of 16 rows x 32 bytes.
+        // until phase 2 of the next K-tile) so that every store instruction writes 4 rows x 256 contiguous bytes
+        // instead of 16 rows x 32 bytes.
         {
             const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
             const int t0 = tm << 8, f0 = tn << 8;
@@ -524,41 +528,38 @@ __global__ void __launch_bounds__(512, 1) gemm256p_kernel(GemmArgs g) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
             } else if (EPI == EPI_STORE16 || EPI == EPI_GELU16 || EPI == EPI_QGELU16) {
-                char *scratch = smem + ((gk - 1) & 1) * 4 * HALF_BYTES + 2 * HALF_BYTES + wc * 8192;
+                // 4 KiB of wave-private scratch each (8 waves = the 32 KiB X region), one 16-token column per pass
+                char *scratch = smem + ((gk - 1) & 1) * 4 * HALF_BYTES + 2 * HALF_BYTES + (wr * 4 + wc) * 4096;
                 const int fw = f0 + wr * 128;
                 float4 b4[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) b4[i] = *reinterpret_cast<const float4 *>(bias_lds + fw + 16 * i + 4 * h);
+                const int wsw = (r16 & 7) << 4;
 #pragma unroll
-                for (int p = 0; p < 2; ++p) {
+                for (int p = 0; p < 4; ++p) {
 #pragma unroll
-                    for (int jj = 0; jj < 2; ++jj) {
-                        const int row = 16 * jj + r16;
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            const f32x4 a = acc[i][2 * p + jj];
-                            f32x2 v01 = {a[0] + b4[i].x, a[1] + b4[i].y}, v23 = {a[2] + b4[i].z, a[3] + b4[i].w};
-                            if (EPI == EPI_GELU16) {
-                                v01 = gelu_erf2(v01);
-                                v23 = gelu_erf2(v23);
-                            }
-                            if (EPI == EPI_QGELU16) {
-                                v01 = f32x2{quick_gelu(v01.x), quick_gelu(v01.y)};
-                                v23 = f32x2{quick_gelu(v23.x), quick_gelu(v23.y)};
-                            }
-                            const uint16_t o[4] = {E::from_float(v01.x), E::from_float(v01.y), E::from_float(v23.x),
-                                                   E::from_float(v23.y)};
-                            uint2 pk;
-                            __builtin_memcpy(&pk, o, 8);
-                            const int col_b = (32 * i + 8 * h) ^ ((row & 7) << 4);  // byte offset in the 256-B row
-                            *reinterpret_cast<uint2 *>(scratch + row * 256 + col_b) = pk;
+                    for (int i = 0; i < 8; ++i) {
+                        const f32x4 a = acc[i][p];
+                        f32x2 v01 = {a[0] + b4[i].x, a[1] + b4[i].y}, v23 = {a[2] + b4[i].z, a[3] + b4[i].w};
+                        if (EPI == EPI_GELU16) {
+                            v01 = gelu_erf2(v01);
+                            v23 = gelu_erf2(v23);
                         }
+                        if (EPI == EPI_QGELU16) {
+                            v01 = f32x2{quick_gelu(v01.x), quick_gelu(v01.y)};
+                            v23 = f32x2{quick_gelu(v23.x), quick_gelu(v23.y)};
+                        }
+                        const uint16_t o[4] = {E::from_float(v01.x), E::from_float(v01.y), E::from_float(v23.x),
+                                               E::from_float(v23.y)};
+                        uint2 pk;
+                        __builtin_memcpy(&pk, o, 8);
+                        *reinterpret_cast<uint2 *>(scratch + r16 * 256 + ((32 * i + 8 * h) ^ wsw)) = pk;
                     }
 #pragma unroll
-                    for (int it = 0; it < 8; ++it) {
+                    for (int it = 0; it < 4; ++it) {
                         const int c = it * 64 + lane, row = c >> 4, ch = c & 15;
                         const uint4 v = *reinterpret_cast<const uint4 *>(scratch + row * 256 + ((ch ^ (row & 7)) << 4));
-                        const int t = t0 + wc * 64 + 32 * p + row;
+                        const int t = t0 + wc * 64 + 16 * p + row;
                         if (ABL & 8) {
                             asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
                         } else if (t < M) {
@@ -577,6 +578,7 @@ __global__ void __launch_bounds__(512, 1) gemm256p_kernel(GemmArgs g) {
                 }
             }
         }
+        if (wr == 1) VM_BAR();
         if (!has_next) break;
         zero_acc();
         tile = next_tile;
