@@ -169,6 +169,9 @@ enum vm_prof_cat {
 };
 int vm_profile_enable(vm_ctx *ctx, int max_events);   /* 0 disables and frees the pool */
 int vm_profile_read(vm_ctx *ctx, double *total_ms_host /*[VM_PROF_NCAT]*/, int64_t *launches_host /*[VM_PROF_NCAT]*/);
+/* Restrict event recording to the categories whose bit (1u << vm_prof_cat) is set (default: all).  Two event
+ * records cost several microseconds per launch on this stack, so a timed run enables only the kernel it reports. */
+int vm_profile_mask(vm_ctx *ctx, uint32_t category_mask);
 
 #ifdef __cplusplus
 }

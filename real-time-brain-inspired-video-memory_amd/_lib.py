@@ -28,7 +28,7 @@ SYMBOLS = [
     "vm_memory_create", "vm_memory_destroy", "vm_memory_append", "vm_memory_size", "vm_memory_capacity",
     "vm_memory_dim", "vm_memory_reset", "vm_memory_rows",
     "vm_topk_workspace_bytes", "vm_topk_cosine", "vm_topk_exact_workspace_bytes", "vm_topk_cosine_exact",
-    "vm_cosine_exact", "vm_topk_merge", "vm_profile_enable", "vm_profile_read",
+    "vm_cosine_exact", "vm_topk_merge", "vm_profile_enable", "vm_profile_read", "vm_profile_mask",
 ]
 PROF_CATS = ["preprocess", "gemm_patch", "gemm_qkv", "gemm_act", "gemm_resid", "attention", "layernorm", "pool",
              "append", "topk_scan", "topk_finalize", "topk_exact", "topk_merge"]
@@ -90,6 +90,7 @@ def lib() -> C.CDLL:
         "vm_topk_merge": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp]),
         "vm_profile_enable": (i32, [vp, i32]),
         "vm_profile_read": (i32, [vp, C.POINTER(f64), C.POINTER(i64)]),
+        "vm_profile_mask": (i32, [vp, C.c_uint32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError here = header/library drift: fail loudly
@@ -121,6 +122,11 @@ class Context:
 
     def profile_enable(self, max_events: int) -> None:
         self.check(self.L.vm_profile_enable(self.handle, int(max_events)))
+
+    def profile_mask(self, categories=None) -> None:
+        """Record events only for these category names (None = all)."""
+        mask = 0xFFFFFFFF if categories is None else sum(1 << PROF_CATS.index(c) for c in categories)
+        self.check(self.L.vm_profile_mask(self.handle, mask))
 
     def profile_read(self) -> dict:
         """{category: (total_ms, launches)} since the last read (synchronises the device)."""

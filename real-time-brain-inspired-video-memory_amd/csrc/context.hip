@@ -28,6 +28,7 @@ extern "C" int vm_init(int device, vm_ctx **out) {
     vm_ctx *ctx = new vm_ctx();
     memset(ctx, 0, sizeof(*ctx));
     ctx->device = device;
+    ctx->prof_mask = 0xffffffffu;
     ctx->num_cus = prop.multiProcessorCount;
     ctx->err[0] = 0;
     *out = ctx;
@@ -59,6 +60,12 @@ extern "C" int vm_profile_enable(vm_ctx *ctx, int max_events) {
     ctx->prof_cat = new int[max_events];
     for (int i = 0; i < 2 * max_events; ++i) VM_HIP(ctx, hipEventCreate(&ctx->prof_ev[i]));
     ctx->prof_cap = max_events;
+    return VM_OK;
+}
+
+extern "C" int vm_profile_mask(vm_ctx *ctx, uint32_t category_mask) {
+    if (!ctx) return VM_ERR_INVALID;
+    ctx->prof_mask = category_mask;
     return VM_OK;
 }
 

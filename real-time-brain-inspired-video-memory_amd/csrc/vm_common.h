@@ -17,6 +17,7 @@ struct vm_ctx {
     hipEvent_t *prof_ev;
     int *prof_cat;
     int prof_cap, prof_n;
+    uint32_t prof_mask;
     double prof_ms[VM_PROF_NCAT];
     int64_t prof_launches[VM_PROF_NCAT];
 };
@@ -27,7 +28,7 @@ struct vm_prof_scope {
     hipStream_t st;
     int slot;
     vm_prof_scope(vm_ctx *c, int cat, hipStream_t s) : ctx(c), st(s), slot(-1) {
-        if (c && c->prof_ev && c->prof_n < c->prof_cap) {
+        if (c && c->prof_ev && c->prof_n < c->prof_cap && ((c->prof_mask >> cat) & 1u)) {
             slot = c->prof_n++;
             c->prof_cat[slot] = cat;
             (void)hipEventRecord(c->prof_ev[2 * slot], s);
