@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--no-knn", action="store_true")
     ap.add_argument("--knn-rows", type=int, default=1_000_000)
     ap.add_argument("--no-streaming", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI); gloo only to rehearse N>1 on one GPU")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--stream-rows", type=int, default=2_097_152, help="rolling memory rows of the C5 latency leg")
     return ap.parse_args()
@@ -80,11 +81,16 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if args.backend == "gloo":
+        local_rank = local_rank % max(1, torch.cuda.device_count())  # rehearsal: ranks may share a GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     import vidmem  # noqa: F401
     from vidmem import specs, synthetic as syn, _lib
@@ -152,7 +158,7 @@ def main():
     ctx.profile_mask(None)
     uncert = retriever.uncertified_total()
 
-    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    t = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())

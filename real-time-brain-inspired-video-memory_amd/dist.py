@@ -40,20 +40,29 @@ class ShardedRetriever:
         """queries [F, D] (this rank's) -> global top-k (scores [F,k] fp64, global rows [F,k] int64)."""
         if self.world == 1:
             return self._local_topk(queries, k, 1, 0)
-        import torch.distributed as dist
         F = queries.shape[0]
-        q_all = torch.empty((self.world * F,) + tuple(queries.shape[1:]), dtype=queries.dtype,
-                            device=queries.device)
-        dist.all_gather_into_tensor(q_all, queries.contiguous(), group=self.group)
+        q_all = self._all_gather(queries)                                   # [world*F, D], rank-major
         s_loc, r_loc = self._local_topk(q_all, k, self.world, self.rank)
         QA = s_loc.shape[0]
-        s_cat = torch.empty((self.world * QA, k), dtype=s_loc.dtype, device=s_loc.device)  # rank-major concatenation
-        r_cat = torch.empty((self.world * QA, k), dtype=r_loc.dtype, device=r_loc.device)
-        dist.all_gather_into_tensor(s_cat, s_loc.contiguous(), group=self.group)
-        dist.all_gather_into_tensor(r_cat, r_loc.contiguous(), group=self.group)
-        s_all, r_all = s_cat.view(self.world, QA, k), r_cat.view(self.world, QA, k)
+        s_all = self._all_gather(s_loc).view(self.world, QA, k)
+        r_all = self._all_gather(r_loc).view(self.world, QA, k)
         lo = self.rank * F
         return self._merge(s_all[:, lo:lo + F].contiguous(), r_all[:, lo:lo + F].contiguous())
+
+    def _all_gather(self, t: torch.Tensor) -> torch.Tensor:
+        """Rank-major concatenation along dim 0.  RCCL gathers device tensors in place; under a gloo group (CPU tests,
+        single-GPU rehearsal of the N>1 path) device tensors are staged through the host, since gloo has no device
+        all-gather."""
+        import torch.distributed as dist
+        t = t.contiguous()
+        out_shape = (self.world * t.shape[0],) + tuple(t.shape[1:])
+        if t.is_cuda and dist.get_backend(self.group) == "gloo":
+            host = torch.empty(out_shape, dtype=t.dtype)
+            dist.all_gather_into_tensor(host, t.cpu(), group=self.group)
+            return host.to(t.device)
+        out = torch.empty(out_shape, dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t, group=self.group)
+        return out
 
     def uncertified_total(self) -> int:
         """Queries (since the last certified call) whose fast-path answer could not be proven exhaustive."""
