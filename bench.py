@@ -219,29 +219,36 @@ def main():
             n = min(250_000, Mk - lo)
             x = torch.randn((n, D), generator=gk, device=dev, dtype=torch.float32)
             big.append((x / x.norm(dim=1, keepdim=True)).to(torch.float16))
-        q = torch.randn((16, D), generator=gk, device=dev, dtype=torch.float32).to(torch.float16)
-        for _ in range(3):
-            big.topk(q, k, check_certified=False)
-        torch.cuda.synchronize()
-        ctx.profile_enable(256)
-        reps = 50
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            big.topk(q, k, check_certified=False)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        p2 = ctx.profile_read()
-        ctx.profile_enable(0)
-        scan_ms = p2["topk_scan"][0] / reps
+        out["knn"] = {"index": f"{Mk} x {D} f16", "k": k, "batches": {}}
         bytes_scan = Mk * D * 2
-        out["knn"] = {
-            "index": f"{Mk} x {D} f16", "Q": 16, "k": k, "queries_per_s": 16 * reps / dt,
-            "ms_per_launch": 1e3 * dt / reps, "scan_kernel_ms": scan_ms,
-            "finalize_kernel_ms": p2["topk_finalize"][0] / reps,
-            "roofline": {"bound": "hbm", "kernel": "topk_scan_kernel", "achieved": bytes_scan / (scan_ms * 1e-3) / 1e9,
-                         "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": bytes_scan / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None},
-        }
+        for Qk in (16, 64):
+            q = torch.randn((Qk, D), generator=gk, device=dev, dtype=torch.float32).to(torch.float16)
+            for _ in range(3):
+                big.topk(q, k, check_certified=False)
+            torch.cuda.synchronize()
+            reps = 50
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                big.topk(q, k, check_certified=False)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            ctx.profile_enable(8 * reps)          # kernel split from a separate, event-bracketed pass
+            for _ in range(reps):
+                big.topk(q, k, check_certified=False)
+            p2 = ctx.profile_read()
+            ctx.profile_enable(0)
+            scan_ms = p2["topk_scan"][0] / reps
+            out["knn"]["batches"][f"Q{Qk}"] = {
+                "queries_per_s": Qk * reps / dt, "ms_per_launch": 1e3 * dt / reps, "scan_kernels_ms": scan_ms,
+                "finalize_kernels_ms": p2["topk_finalize"][0] / reps, "scan_GBps": bytes_scan / (scan_ms * 1e-3) / 1e9,
+            }
+        best = max(out["knn"]["batches"].values(), key=lambda v: v["queries_per_s"])
+        q16 = out["knn"]["batches"]["Q16"]
+        out["knn"]["queries_per_s"] = best["queries_per_s"]
+        out["knn"]["uncertified_queries"] = int(big._uncert.item())
+        out["knn"]["roofline"] = {"bound": "hbm", "kernel": "topk_scan_kernel<f16, KL=16, QT=1> (Q=16)",
+                                  "achieved": q16["scan_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                  "frac": q16["scan_GBps"] / HBM_PEAK_GBPS, "traffic": None}
         big.close()
 
     # ---- streaming leg (BASELINE configs[4]): 16 x 1080p frames per chunk, rolling 2M-row memory, one hipGraph ------

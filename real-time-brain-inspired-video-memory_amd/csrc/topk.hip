@@ -76,7 +76,8 @@ template <int DT, int KL, int QT>
 __global__ void __launch_bounds__(SCAN_THREADS)
     topk_scan_kernel(const uint16_t *__restrict__ mem, const float *__restrict__ rnorm,
                      const uint16_t *__restrict__ queries, const int64_t *__restrict__ d_total, int64_t cap,
-                     int ring, int D, int Q, int q_pad, float *__restrict__ part_s, int *__restrict__ part_o) {
+                     int ring, int D, int Q, int q_pad, float *__restrict__ part_s, int *__restrict__ part_o,
+                     int64_t row_limit, const float *__restrict__ thr_s, const int *__restrict__ thr_o) {
     using E = vm_elem<DT>;
     using vec8 = typename E::vec8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -110,9 +111,20 @@ __global__ void __launch_bounds__(SCAN_THREADS)
             lo[t][i] = INT_MAX;
         }
 
-    const RingView rv = ring_view(*d_total, cap, ring);
+    RingView rv = ring_view(*d_total, cap, ring);
+    if (rv.n > row_limit) rv.n = row_limit;  // the sampling pre-pass scans only the first row_limit slots
     const int64_t ntiles = (rv.n + 15) / 16;
     const int ksteps = D / 32;  // multiple of 4
+    // Optional per-query cut (score, order) from the sampling pre-pass: the KL-th best of a SUBSET of the rows.  At
+    // least KL rows are at least that good, so anything strictly worse cannot be in the top KL and skips the insert.
+    float ts[QT];
+    int to[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const bool have = thr_s && q0 + 16 * t + r16 < Q;
+        ts[t] = have ? thr_s[q0 + 16 * t + r16] : -INFINITY;
+        to[t] = have ? thr_o[q0 + 16 * t + r16] : INT_MAX;
+    }
 
     for (int64_t tile = (int64_t)blockIdx.x * nw + wave; tile < ntiles; tile += (int64_t)gridDim.x * nw) {
         int64_t row = tile * 16 + r16;
@@ -154,7 +166,8 @@ __global__ void __launch_bounds__(SCAN_THREADS)
 #pragma unroll
             for (int t = 0; t < QT; ++t) {
                 const float s = valid ? acc[t][j] * rnv[j] : -INFINITY;
-                if (valid && better(s, o, ls[t][KL - 1], lo[t][KL - 1])) list_insert<KL>(ls[t], lo[t], s, o);
+                if (valid && !better(ts[t], to[t], s, o) && better(s, o, ls[t][KL - 1], lo[t][KL - 1]))
+                    list_insert<KL>(ls[t], lo[t], s, o);
             }
         }
     }
@@ -235,14 +248,16 @@ __global__ void __launch_bounds__(SCAN_THREADS)
 // ---------------------------------------------------------------------------------------------------------
 // finalize
 // ---------------------------------------------------------------------------------------------------------
-template <int DT, int KL>
+// THRESH: stop after the fp32 ranking and publish the KL-th best (score, order) per query for the main scan
+template <int DT, int KL, bool THRESH>
 __global__ void __launch_bounds__(FIN_THREADS)
     topk_finalize_kernel(const uint16_t *__restrict__ mem, const double *__restrict__ norm64,
                          const uint16_t *__restrict__ queries, const int64_t *__restrict__ d_total, int64_t cap,
                          int ring, int D, int q_pad, int nblk, const float *__restrict__ part_s,
                          const int *__restrict__ part_o, int k, int use_min, double min_score, int score_mode,
                          int64_t row_stride, int64_t row_offset, double *__restrict__ out_scores,
-                         int64_t *__restrict__ out_rows, int *__restrict__ uncertified) {
+                         int64_t *__restrict__ out_rows, int *__restrict__ uncertified,
+                         float *__restrict__ thr_s_out, int *__restrict__ thr_o_out) {
     using E = vm_elem<DT>;
     __shared__ float hs[MAX_BLOCKS];
     __shared__ int ho[MAX_BLOCKS];
@@ -372,6 +387,13 @@ __global__ void __launch_bounds__(FIN_THREADS)
     }
     __syncthreads();
     const int nfin = C < KL ? C : KL;
+    if (THRESH) {
+        if (tid == 0) {
+            thr_s_out[q] = C >= KL ? fs[KL - 1] : -INFINITY;
+            thr_o_out[q] = C >= KL ? fo[KL - 1] : INT_MAX;
+        }
+        return;
+    }
 
     // exact re-scoring.  TPC = 256/KL threads share one candidate.
     //  * fp16 rows with |q||m| < 32: fp16 x fp16 products are exact multiples of 2^-48 and every partial sum stays
@@ -575,62 +597,93 @@ ScanPlan make_plan(const vm_memory *m, int Q, int k) {
     return p;
 }
 
+constexpr int64_t SAMPLE_ROWS = 16384;  // rows of the sampling pre-pass (multi-tile query groups only)
+
 template <int DT, int KL, int QT>
-int launch_scan(vm_memory *m, const ScanPlan &p, const void *queries, int Q, float *part_s, int *part_o,
-                hipStream_t st) {
+int launch_scan(vm_memory *m, const ScanPlan &p, int nblk, int64_t row_limit, const float *thr_s, const int *thr_o,
+                const void *queries, int Q, float *part_s, int *part_o, hipStream_t st) {
     auto kern = topk_scan_kernel<DT, KL, QT>;
     if (p.lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)p.lds);
         if (e != hipSuccess) return vm_fail(m->ctx, VM_ERR_HIP, "LDS opt-in %zu: %s", p.lds, hipGetErrorString(e));
     }
-    dim3 grid(p.nblk, p.qgroups);
+    dim3 grid(nblk, p.qgroups);
     vm_prof_scope prof(m->ctx, VM_PROF_TOPK_SCAN, st);
     kern<<<grid, SCAN_THREADS, p.lds, st>>>(m->rows, m->rnorm32, (const uint16_t *)queries, m->d_total, m->cap,
-                                          m->ring, m->D, Q, p.q_pad, part_s, part_o);
+                                          m->ring, m->D, Q, p.q_pad, part_s, part_o, row_limit, thr_s, thr_o);
     VM_LAUNCH_CHECK(m->ctx);
     return VM_OK;
 }
 
 template <int DT, int KL>
-int launch_scan_qt(vm_memory *m, const ScanPlan &p, const void *queries, int Q, float *part_s, int *part_o,
-                   hipStream_t st) {
+int launch_scan_qt(vm_memory *m, const ScanPlan &p, int nblk, int64_t row_limit, const float *thr_s,
+                   const int *thr_o, const void *queries, int Q, float *part_s, int *part_o, hipStream_t st) {
     if constexpr (KL <= 16) {
-        if (p.cfg.QT == 4) return launch_scan<DT, KL, 4>(m, p, queries, Q, part_s, part_o, st);
+        if (p.cfg.QT == 4)
+            return launch_scan<DT, KL, 4>(m, p, nblk, row_limit, thr_s, thr_o, queries, Q, part_s, part_o, st);
     }
     if constexpr (KL <= 32) {
-        if (p.cfg.QT == 2) return launch_scan<DT, KL, 2>(m, p, queries, Q, part_s, part_o, st);
+        if (p.cfg.QT == 2)
+            return launch_scan<DT, KL, 2>(m, p, nblk, row_limit, thr_s, thr_o, queries, Q, part_s, part_o, st);
     }
-    return launch_scan<DT, KL, 1>(m, p, queries, Q, part_s, part_o, st);
+    return launch_scan<DT, KL, 1>(m, p, nblk, row_limit, thr_s, thr_o, queries, Q, part_s, part_o, st);
+}
+
+template <int DT, int KL>
+int run_topk_kl(vm_memory *m, const ScanPlan &p, const void *queries, int Q, int k, int use_min, double min_score,
+                int score_mode, int64_t row_stride, int64_t row_offset, double *out_scores, int64_t *out_rows,
+                int *uncertified, float *part_s, int *part_o, float *thr_s, int *thr_o, hipStream_t st) {
+    int rc;
+    const float *use_ts = nullptr;
+    const int *use_to = nullptr;
+    // Multi-tile query groups are insert-bound, not HBM-bound: a cheap pre-pass over the first SAMPLE_ROWS slots
+    // gives every query a valid cut (the KL-th best of that subset), and the full scan then skips the sorted insert
+    // for everything below it.
+    if (p.cfg.QT >= 2 && m->cap >= 8 * SAMPLE_ROWS) {
+        const int nw = SCAN_THREADS / 64;
+        int nblk_pre = (int)((SAMPLE_ROWS / 16 + nw - 1) / nw);
+        if (nblk_pre > p.nblk) nblk_pre = p.nblk;
+        if ((rc = launch_scan_qt<DT, KL>(m, p, nblk_pre, SAMPLE_ROWS, nullptr, nullptr, queries, Q, part_s, part_o,
+                                         st)) != VM_OK)
+            return rc;
+        {
+            vm_prof_scope prof(m->ctx, VM_PROF_TOPK_FINALIZE, st);
+            topk_finalize_kernel<DT, KL, true><<<Q, FIN_THREADS, (size_t)m->D * 2, st>>>(
+                m->rows, m->norm64, (const uint16_t *)queries, m->d_total, m->cap, m->ring, m->D, p.q_pad, nblk_pre,
+                part_s, part_o, k, use_min, min_score, score_mode, row_stride, row_offset, out_scores, out_rows,
+                nullptr, thr_s, thr_o);
+            VM_LAUNCH_CHECK(m->ctx);
+        }
+        use_ts = thr_s;
+        use_to = thr_o;
+    }
+    if ((rc = launch_scan_qt<DT, KL>(m, p, p.nblk, INT64_MAX, use_ts, use_to, queries, Q, part_s, part_o, st)) !=
+        VM_OK)
+        return rc;
+    vm_prof_scope prof(m->ctx, VM_PROF_TOPK_FINALIZE, st);
+    topk_finalize_kernel<DT, KL, false><<<Q, FIN_THREADS, (size_t)m->D * 2, st>>>(
+        m->rows, m->norm64, (const uint16_t *)queries, m->d_total, m->cap, m->ring, m->D, p.q_pad, p.nblk, part_s,
+        part_o, k, use_min, min_score, score_mode, row_stride, row_offset, out_scores, out_rows, uncertified, nullptr,
+        nullptr);
+    VM_LAUNCH_CHECK(m->ctx);
+    return VM_OK;
 }
 
 template <int DT>
 int run_topk(vm_memory *m, const ScanPlan &p, const void *queries, int Q, int k, int use_min, double min_score,
              int score_mode, int64_t row_stride, int64_t row_offset, double *out_scores, int64_t *out_rows,
-             int *uncertified, float *part_s, int *part_o, hipStream_t st) {
-    int rc;
+             int *uncertified, float *part_s, int *part_o, float *thr_s, int *thr_o, hipStream_t st) {
+#define GO(KLV)                                                                                                   \
+    return run_topk_kl<DT, KLV>(m, p, queries, Q, k, use_min, min_score, score_mode, row_stride, row_offset,      \
+                                out_scores, out_rows, uncertified, part_s, part_o, thr_s, thr_o, st)
     switch (p.cfg.KL) {
-        case 8: rc = launch_scan_qt<DT, 8>(m, p, queries, Q, part_s, part_o, st); break;
-        case 16: rc = launch_scan_qt<DT, 16>(m, p, queries, Q, part_s, part_o, st); break;
-        case 32: rc = launch_scan_qt<DT, 32>(m, p, queries, Q, part_s, part_o, st); break;
-        default: rc = launch_scan_qt<DT, 64>(m, p, queries, Q, part_s, part_o, st); break;
+        case 8: GO(8);
+        case 16: GO(16);
+        case 32: GO(32);
+        default: GO(64);
     }
-    if (rc != VM_OK) return rc;
-    vm_prof_scope prof(m->ctx, VM_PROF_TOPK_FINALIZE, st);
-#define FIN(KLV)                                                                                           \
-    topk_finalize_kernel<DT, KLV><<<Q, FIN_THREADS, (size_t)m->D * 2, st>>>(                                              \
-        m->rows, m->norm64, (const uint16_t *)queries, m->d_total, m->cap, m->ring, m->D, p.q_pad, p.nblk, \
-        part_s, part_o, k, use_min, min_score, score_mode, row_stride, row_offset, out_scores, out_rows,   \
-        uncertified)
-    switch (p.cfg.KL) {
-        case 8: FIN(8); break;
-        case 16: FIN(16); break;
-        case 32: FIN(32); break;
-        default: FIN(64); break;
-    }
-#undef FIN
-    VM_LAUNCH_CHECK(m->ctx);
-    return VM_OK;
+#undef GO
 }
 
 }  // namespace
@@ -638,7 +691,7 @@ int run_topk(vm_memory *m, const ScanPlan &p, const void *queries, int Q, int k,
 extern "C" size_t vm_topk_workspace_bytes(const vm_memory *m, int Q, int k) {
     if (!m || Q <= 0 || k <= 0 || k > 58) return 0;
     const ScanPlan p = make_plan(m, Q, k);
-    return 2 * p.part_bytes + 256;
+    return 2 * p.part_bytes + vm_align_up((size_t)p.q_pad * 8, 256) + 256;
 }
 
 extern "C" int vm_topk_cosine(vm_memory *m, const void *queries, int Q, int k, int use_min_score,
@@ -654,19 +707,21 @@ extern "C" int vm_topk_cosine(vm_memory *m, const void *queries, int Q, int k, i
     if (score_mode != VM_SCORE_RAW && score_mode != VM_SCORE_UNIT_INTERVAL)
         return vm_fail(ctx, VM_ERR_INVALID, "bad score_mode %d", score_mode);
     const ScanPlan p = make_plan(m, Q, k);
-    if (!workspace || workspace_bytes < 2 * p.part_bytes)
-        return vm_fail(ctx, VM_ERR_NOMEM, "vm_topk_cosine: workspace %zu < %zu", workspace_bytes,
-                       2 * p.part_bytes);
+    const size_t need = 2 * p.part_bytes + vm_align_up((size_t)p.q_pad * 8, 256);
+    if (!workspace || workspace_bytes < need)
+        return vm_fail(ctx, VM_ERR_NOMEM, "vm_topk_cosine: workspace %zu < %zu", workspace_bytes, need);
     if (((uintptr_t)workspace & 15) || ((uintptr_t)queries & 15))
         return vm_fail(ctx, VM_ERR_INVALID, "vm_topk_cosine: pointers must be 16-byte aligned");
     float *part_s = (float *)workspace;
     int *part_o = (int *)((char *)workspace + p.part_bytes);
+    float *thr_s = (float *)((char *)workspace + 2 * p.part_bytes);
+    int *thr_o = (int *)(thr_s + p.q_pad);
     hipStream_t st = (hipStream_t)stream;
     if (m->dtype == VM_F16)
         return run_topk<VM_F16>(m, p, queries, Q, k, use_min_score, min_score, score_mode, row_stride,
-                                row_offset, out_scores, out_rows, out_uncertified, part_s, part_o, st);
+                                row_offset, out_scores, out_rows, out_uncertified, part_s, part_o, thr_s, thr_o, st);
     return run_topk<VM_BF16>(m, p, queries, Q, k, use_min_score, min_score, score_mode, row_stride, row_offset,
-                             out_scores, out_rows, out_uncertified, part_s, part_o, st);
+                             out_scores, out_rows, out_uncertified, part_s, part_o, thr_s, thr_o, st);
 }
 
 extern "C" int vm_topk_merge(vm_ctx *ctx, const double *scores, const int64_t *rows, int parts, int Q, int k,
