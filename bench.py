@@ -132,7 +132,8 @@ def main():
 
     # per-kernel breakdown: ONE extra untimed step with every launch bracketed by HIP events (two event records cost
     # ~7 us per launch here, 12 % of the step, so the timed region records only the dominant kernel's events)
-    passes = -(-F // ((256 // (spec["hidden"] // 256)) * 256 // enc.tokens))
+    mb_frames = int(os.environ.get("VIDMEM_MICROBATCH", "0")) or (256 // (spec["hidden"] // 256)) * 256 // enc.tokens
+    passes = -(-F // mb_frames)
     per_step_events = passes * (7 * spec["layers"] + 8) + 16
     ctx.profile_enable(per_step_events + 64)
     step(args.warmup)
