@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--chunks-per-step", type=int, default=55,
-                    help="chunks of 16 frames encoded per step per GPU (55 chunks = 880 frames = 8 encoder passes of 110)")
+                    help="chunks of 16 frames encoded per step per GPU (55 chunks = 880 frames = 2 encoder passes of 440)")
     ap.add_argument("--memory-rows", type=int, default=100_000, help="rows of the memory shard per GPU")
     ap.add_argument("--topk", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -132,7 +132,7 @@ def main():
 
     # per-kernel breakdown: ONE extra untimed step with every launch bracketed by HIP events (two event records cost
     # ~7 us per launch here, 12 % of the step, so the timed region records only the dominant kernel's events)
-    mb_frames = int(os.environ.get("VIDMEM_MICROBATCH", "0")) or (256 // (spec["hidden"] // 256)) * 256 // enc.tokens
+    mb_frames = int(os.environ.get("VIDMEM_MICROBATCH", "0")) or 4 * (256 // (spec["hidden"] // 256)) * 256 // enc.tokens
     passes = -(-F // mb_frames)
     per_step_events = passes * (7 * spec["layers"] + 8) + 16
     ctx.profile_enable(per_step_events + 64)
@@ -183,7 +183,7 @@ def main():
         T = enc.tokens
         H, M = spec["hidden"], spec["mlp"]
         mbs = []  # micro-batch sizes vm_encode used for F frames (csrc/encoder.hip micro_batch_of)
-        mb = int(os.environ.get("VIDMEM_MICROBATCH", "0")) or (256 // (H // 256)) * 256 // T
+        mb = mb_frames
         left = F
         while left > 0:
             mbs.append(min(mb, left))

@@ -108,15 +108,21 @@ __global__ void __launch_bounds__(256, (NT <= 13 ? 2 : 1))
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         // exp((s - max) / 8) = exp2(s * c - max * c): one fma + one v_exp per score
         const float neg_mxc = -mx * scale_log2e;
-        float sum = 0.f;
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 c2 = {scale_log2e, scale_log2e}, n2 = {neg_mxc, neg_mxc};
+        f32x2 sum2 = {0.f, 0.f};
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][j], scale_log2e, neg_mxc));
-                s[kt][j] = e;
-                sum += e;
-            }
+        for (int kt = 0; kt < NT; ++kt) {
+            // the fma and the running sum on 2-vectors (v_pk_fma_f32 / v_pk_add_f32); v_exp_f32 is scalar
+            f32x2 a01 = __builtin_elementwise_fma(f32x2{s[kt][0], s[kt][1]}, c2, n2);
+            f32x2 a23 = __builtin_elementwise_fma(f32x2{s[kt][2], s[kt][3]}, c2, n2);
+            a01 = f32x2{__builtin_amdgcn_exp2f(a01.x), __builtin_amdgcn_exp2f(a01.y)};
+            a23 = f32x2{__builtin_amdgcn_exp2f(a23.x), __builtin_amdgcn_exp2f(a23.y)};
+            sum2 += a01;
+            sum2 += a23;
+            s[kt] = f32x4{a01.x, a01.y, a23.x, a23.y};
+        }
+        float sum = sum2.x + sum2.y;
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
         const float inv = 1.0f / sum;
@@ -142,10 +148,9 @@ __global__ void __launch_bounds__(256, (NT <= 13 ? 2 : 1))
                 const int coff = ((2 * dt + (tp >> 1)) ^ sw) << 4;
                 const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr)(row_lo + coff));
                 const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr)(row_lo + 16 * 128 + coff));
-                short av[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                vec8 af;
-                __builtin_memcpy(&af, av, 16);
-                o[dt] = E::mfma16(af, pf, o[dt]);
+                typedef short s8v __attribute__((__vector_size__(8 * sizeof(short))));
+                const s8v av = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);  // register pair concatenation
+                o[dt] = E::mfma16(__builtin_bit_cast(vec8, av), pf, o[dt]);
             }
             (void)key_hi;
         }

@@ -424,15 +424,17 @@ extern "C" int vm_encoder_patch_k(const vm_encoder *e) { return e ? e->patch_k :
 extern "C" int vm_encoder_out_dim(const vm_encoder *e) { return e ? e->out_dim : 0; }
 
 static int micro_batch_of(const vm_encoder *e, int B) {
-    // Frames per pass.  The GEMMs use 256 x 256 tiles, one per CU per round: pick the largest batch whose token rows
-    // fill a whole number of rounds for the narrowest GEMM (N = hidden): ceil(mb*T/256) * (hidden/256) <= ~CUs.
-    // ViT-B/16 (T=197, hidden 768): 85 row tiles x 3 = 255 tiles -> 110 frames; CLIP-L/14-336 (T=577, hidden 1024):
-    // 64 x 4 = 256 tiles -> 28 frames.  One pass's activations (~1.5 MB/frame for ViT-B/16) also stay close to the
-    // 256 MiB Infinity Cache between kernels.
+    // Frames per pass.  The GEMMs use 256 x 256 tiles, one per CU per round: pick a batch whose token rows fill a
+    // whole number of rounds for the narrowest GEMM (N = hidden): ceil(mb*T/256) * (hidden/256) = rounds * ~CUs.
+    // ViT-B/16 (T=197, hidden 768): 85 row tiles x 3 = 255 tiles per round -> 110 frames per round;
+    // CLIP-L/14-336 (T=577, hidden 1024): 64 x 4 = 256 tiles -> 28 frames per round.
     int mb = e->micro_batch;
     if (mb <= 0) {
+        // 4 rounds of tiles per launch for the narrowest GEMM: fewer, longer launches amortise the ~6 us of ramp and
+        // tail each of the ~85 kernels of a pass pays (measured +3 % over 1 round); 1.5 GB of workspace is nothing
+        // next to 288 GB of HBM
         const int col_tiles = e->d.hidden / 256;
-        const int row_tiles = e->ctx->num_cus / col_tiles;
+        const int row_tiles = 4 * (e->ctx->num_cus / col_tiles);
         mb = row_tiles * 256 / e->tokens;
         if (mb < 1) mb = 1;
     }

@@ -136,13 +136,15 @@ def test_full_models_match_golden(name, dtype, golden):
     assert (cos > 1 - (5e-5 if dtype == "f16" else 1e-3)).all()  # 16-bit output: |e| is 1 only to ~1 ulp
 
 
-def test_batching_is_invisible():
+def test_batching_is_invisible(monkeypatch):
     """Frame i's embedding must not depend on what else is in the launch or where micro-batches split."""
     from vidmem import synthetic as syn, specs
     spec = dict(specs.VIT_B16_224, layers=2)
     w = syn.encoder_weights(spec, seed=9)
+    monkeypatch.setenv("VIDMEM_MICROBATCH", "64")     # read at encoder creation: 150 frames = passes of 64, 64, 22
     enc = _encoder(spec, w, "f16")
-    frames = torch.from_numpy(syn.frames_u8(99, 150, 224, 224)).cuda()   # > default micro-batch of 128
+    monkeypatch.delenv("VIDMEM_MICROBATCH")
+    frames = torch.from_numpy(syn.frames_u8(99, 150, 224, 224)).cuda()
     all_emb = enc.embed_frames(frames)
     head = enc.embed_frames(frames[:3])
     tail = enc.embed_frames(frames[147:])
