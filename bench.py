@@ -138,12 +138,15 @@ def main():
     ctx.profile_enable(per_step_events + 64)
     step(args.warmup)
     breakdown = ctx.profile_read()
-    gemm_cats = ("gemm_patch", "gemm_qkv", "gemm_act", "gemm_resid")
-    dom = max(gemm_cats, key=lambda c: breakdown[c][0])
+    # the two GEMM kernel instantiations, as rocprofv3 names them: the 16-bit-store epilogue (patch embed, QKV,
+    # attention projection, FC2) and the GELU epilogue (FC1)
+    kern_cats = {"gemm256p_kernel<f16, STORE16>": ("gemm_patch", "gemm_qkv", "gemm_resid"),
+                 "gemm256p_kernel<f16, GELU16>": ("gemm_act",)}
+    dom = max(kern_cats, key=lambda kname: sum(breakdown[c][0] for c in kern_cats[kname]))
     ctx.profile_enable(0)
 
     ctx.profile_enable(0 if args.no_profile else args.steps * per_step_events + 64)
-    ctx.profile_mask([dom])
+    ctx.profile_mask(list(kern_cats[dom]))
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -195,14 +198,31 @@ def main():
             "gemm_resid": sum(2.0 * r * H * H + 2.0 * r * H * M for r in rows) * spec["layers"],
             "gemm_patch": sum(2.0 * b * (T - 1) * (3 * 16 * 16) * H for b in mbs),
         }
-        ms, launches = prof[dom]
+        abytes = {  # operands read once + output written once, per step
+            "gemm_qkv": sum(2.0 * (r * H + 3 * H * H + r * 3 * H) for r in rows) * spec["layers"],
+            "gemm_act": sum(2.0 * (r * H + M * H + r * M) for r in rows) * spec["layers"],
+            "gemm_resid": sum(2.0 * (r * H + H * H + r * H) + 2.0 * (r * M + H * M + r * H) for r in rows) * spec["layers"],
+            "gemm_patch": sum(2.0 * (b * (T - 1) * 768 + 768 * H + b * (T - 1) * H) for b in mbs),
+        }
+        ms = sum(prof[c][0] for c in kern_cats[dom])
+        launches = sum(prof[c][1] for c in kern_cats[dom])
         nsteps_prof = args.steps if not args.no_profile else 1
-        achieved = flops[dom] * nsteps_prof / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        dom_flops = sum(flops[c] for c in kern_cats[dom])          # algorithmic FLOPs of those launches per step
+        achieved = dom_flops * nsteps_prof / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        traffic = None   # HBM/fabric bytes per launch from separate rocprofv3 --pmc passes (tools/pmc_traffic.py)
+        tpath = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+        if os.path.exists(tpath) and not os.environ.get("VIDMEM_MICROBATCH"):
+            rocname = "void (anonymous namespace)::gemm256p_kernel<0, %d, 0>" % (0 if "STORE16" in dom else 1)
+            traffic = json.load(open(tpath))["kernels"].get(rocname, {}).get("traffic_bytes")
         out["roofline"] = {
-            "bound": "mfma", "kernel": f"gemm256p_kernel<f16, store16> [{dom}]", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": None,
+            "bound": "mfma", "kernel": dom, "achieved": achieved, "peak": MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic,
+            "traffic_note": "HBM/fabric bytes per launch = 2*FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc "
+                            "passes of this bench (profiles/r1_pmc_traffic.json); algorithmic_bytes = operands + "
+                            "output once per launch",
+            "algorithmic_bytes": sum(abytes[c] for c in kern_cats[dom]) / max(launches / nsteps_prof, 1),
             "avg_launch_ms": ms / max(launches, 1), "launches": launches,
-            "flops_per_launch": flops[dom] * nsteps_prof / max(launches, 1),
+            "flops_per_launch": dom_flops * nsteps_prof / max(launches, 1),
         }
         out["kernel_time_ms_per_step"] = {c: round(v[0], 4) for c, v in breakdown.items() if v[1]}
         out["kernel_time_note"] = "one untimed step with every launch event-bracketed (adds ~7 us per launch)"
