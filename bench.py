@@ -269,7 +269,12 @@ def main():
         out["knn"]["uncertified_queries"] = int(big._uncert.item())
         out["knn"]["roofline"] = {"bound": "hbm", "kernel": "topk_scan_kernel<f16, KL=16, QT=1> (Q=16)",
                                   "achieved": q16["scan_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                  "frac": q16["scan_GBps"] / HBM_PEAK_GBPS, "traffic": None}
+                                  "frac": q16["scan_GBps"] / HBM_PEAK_GBPS, "traffic": None,
+                                  "algorithmic_bytes": bytes_scan}
+        tpath = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+        if os.path.exists(tpath) and Mk == 1_000_000:
+            tk = json.load(open(tpath))["kernels"].get("void (anonymous namespace)::topk_scan_kernel<0, 16, 1>", {})
+            out["knn"]["roofline"]["traffic"] = tk.get("traffic_bytes")
         big.close()
 
     # ---- streaming leg (BASELINE configs[4]): 16 x 1080p frames per chunk, rolling 2M-row memory, one hipGraph ------
@@ -283,13 +288,15 @@ def main():
             x = torch.randn((n, D), generator=gs, device=dev, dtype=torch.float32)
             ring.append((x / x.norm(dim=1, keepdim=True)).to(torch.float16))
         sess = StreamingSession(enc, ring, 16, 1080, 1920, top_k=k, warmup=2)
-        chunks = torch.randint(0, 256, (4, 16, 1080, 1920, 3), generator=gs, device=dev, dtype=torch.uint8)
+        chunk = torch.empty((16, 1080, 1920, 3), device=dev, dtype=torch.uint8)
         lat = []
         for i in range(60):
+            chunk.random_(0, 256, generator=gs)   # a new chunk every push (repeats would plant exact ties)
+            torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             with torch.cuda.stream(sess.stream):
                 e0.record(sess.stream)
-                sess.push(chunks[i % 4])
+                sess.push(chunk)
                 e1.record(sess.stream)
             e1.synchronize()
             lat.append(e0.elapsed_time(e1))
@@ -300,7 +307,7 @@ def main():
             "p50_ms": lat[len(lat) // 2], "p99_ms": lat[min(len(lat) - 1, int(len(lat) * 0.99))], "max_ms": lat[-1],
             "budget_ms": 33.0, "replays": len(lat), "uncertified_queries": int(ring._uncert.item()),
         }
-        del sess, chunks
+        del sess, chunk
         ring.close()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
