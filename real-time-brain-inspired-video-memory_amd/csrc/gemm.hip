@@ -454,8 +454,21 @@ __global__ void __launch_bounds__(512, 1) gemm256p_kernel(GemmArgs g) {
     if (wr == 1) VM_BAR();  // wave row 1 runs one barrier behind wave row 0
     zero_acc();
 
-    int gk = 0;            // K-tiles consumed so far (selects the LDS buffer)
-    bool after_epi = false;  // this wave has an epilogue's stores behind the LDS-DMA still in flight
+    int gk = 0;  // K-tiles consumed so far (selects the LDS buffer)
+    // State carried across a tile boundary.  The vector-memory pipe of a CU is in order, so the epilogue's 128 KiB of
+    // stores must not sit in front of the next K-tiles' LDS-DMA: at the boundary the SECOND K-tile of the next tile
+    // is staged BEFORE the epilogue (the first was staged during the last K-tile), and the counted waits below skip
+    // over the stores, which then drain under two K-tiles of MFMA work.
+    //   ep = 0: no epilogue behind        ep = 1: epilogue of a full tile (exactly EPI_STORES stores per wave)
+    //   ep = 2: epilogue with an unknown (smaller) store count (ragged last row panel, fp32 epilogues): waits assume
+    //           zero stores, i.e. they also wait for the stores - always safe, rare
+    int ep = 0;
+    bool prestaged = false;  // K-tile 1 of the current tile was staged at the boundary
+#define VM_WAIT_EP(N)                                        \
+    do {                                                     \
+        if (ep == 1) wait_vmcnt<(N) + EPI_STORES>();         \
+        else wait_vmcnt<(N)>();                              \
+    } while (0)
     while (true) {
         const int next_tile = tile + gridDim.x;
         const bool has_next = next_tile < ntiles;
@@ -469,14 +482,18 @@ __global__ void __launch_bounds__(512, 1) gemm256p_kernel(GemmArgs g) {
                 skt = 0;
                 more = true;
             }
+            const bool k0_after = prestaged && kt == 0;  // next K-tile already in flight: nothing to stage here
+            const bool k1_after = prestaged && kt == 1;  // stages K-tile 2 as usual, counts skip the stores
             // phase 1
             read_a(buf, 0);
             read_b(buf, 0);
-            if (more) {
+            if (k0_after) {
+                VM_WAIT_EP(10);  // retire Xb1 of this K-tile; younger: its Wa1 (2) + K-tile 1 (8) [+ stores]
+            } else if (more) {
                 stage_Wa0(skt, nb);
-                if (after_epi) wait_vmcnt<4 + EPI_STORES>(); else wait_vmcnt<4>();
+                if (k1_after) VM_WAIT_EP(4); else wait_vmcnt<4>();
             } else {
-                if (after_epi) wait_vmcnt<EPI_STORES>(); else wait_vmcnt<0>();
+                wait_vmcnt<0>();
             }
             VM_BAR();
             VM_LGKM0();
@@ -484,11 +501,11 @@ __global__ void __launch_bounds__(512, 1) gemm256p_kernel(GemmArgs g) {
             VM_BAR();
             // phase 2
             read_b(buf, 1);
-            if (more) {
+            if (k0_after) {
+                VM_WAIT_EP(8);   // retire Wa1 of this K-tile; younger: K-tile 1 (8) [+ stores]
+            } else if (more) {
                 stage_Xb0(skt, nb);
-                if (after_epi) wait_vmcnt<4 + EPI_STORES>(); else wait_vmcnt<4>();
-            } else if (after_epi) {
-                wait_vmcnt<EPI_STORES>();
+                if (k1_after) VM_WAIT_EP(4); else wait_vmcnt<4>();
             }
             VM_BAR();
             VM_LGKM0();
@@ -496,25 +513,39 @@ __global__ void __launch_bounds__(512, 1) gemm256p_kernel(GemmArgs g) {
             VM_BAR();
             // phase 3
             read_a(buf, 1);
-            if (more) stage_Xb1(skt, nb);
+            if (more && !k0_after) stage_Xb1(skt, nb);
             VM_BAR();
             VM_LGKM0();
             mma(1, 1);
             VM_BAR();
-            // phase 4: retiring Wa0/Xb0 of the staged K-tile also retires every older store
-            if (more) {
+            // phase 4
+            if (k0_after) {
+                VM_WAIT_EP(4);   // retire Wa0 + Xb0 of K-tile 1; younger: its Xb1, Wa1 (4) [+ stores]
+            } else if (more) {
                 stage_Wa1(skt, nb);
-                wait_vmcnt<4>();
+                wait_vmcnt<4>();  // from K-tile 1 on this also retires the epilogue's stores (>= 2 K-tiles old)
+                if (k1_after) ep = 0;
             }
-            after_epi = false;
             VM_BAR();
             mma(1, 0);
             VM_BAR();
         }
+        if (prestaged && nk < 2) ep = 0;
+        prestaged = false;
         // Tile boundary: wave row 0 waits one barrier so that BOTH wave rows run their epilogues in the same interval
         // (their LDS round trips and store issue overlap instead of serialising); wave row 1 takes its matching extra
         // barrier after the epilogue, which also restores the one-barrier offset for the next tile.
         if (wr == 0) VM_BAR();
+        // the consumed buffer is free (every wave's reads of it retired before this barrier): stage K-tile 1 of the
+        // next tile into it NOW, ahead of the epilogue's stores in this CU's in-order memory pipe
+        const bool do_prestage = has_next && nk >= 2;
+        if (do_prestage) {
+            const int cb = (gk + 1) & 1;  // == buffer of the K-tile just consumed
+            stage_Wa0(1, cb);
+            stage_Xb0(1, cb);
+            stage_Xb1(1, cb);
+            stage_Wa1(1, cb);
+        }
         // epilogue.  acc[i][j][e] = out[token t0 + wc*64 + 16j + r16][feature f0 + wr*128 + 16i + 4h + e].
         // 16-bit outputs go through a wave-private LDS transpose (the X region of the buffer just consumed: free
         // until phase 2 of the next K-tile) so that every store instruction writes 4 rows x 256 contiguous bytes
@@ -528,15 +559,17 @@ __global__ void __launch_bounds__(512, 1) gemm256p_kernel(GemmArgs g) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
             } else if (EPI == EPI_STORE16 || EPI == EPI_GELU16 || EPI == EPI_QGELU16) {
-                // 4 KiB of wave-private scratch each (8 waves = the 32 KiB X region), one 16-token column per pass
-                char *scratch = smem + ((gk - 1) & 1) * 4 * HALF_BYTES + 2 * HALF_BYTES + (wr * 4 + wc) * 4096;
+                // 2 KiB of wave-private scratch each in the spare LDS behind the bias table: 8 token rows per pass
+                char *scratch = smem + 8 * HALF_BYTES + ((g.N * 4 + 15) & ~15) + (wr * 4 + wc) * 2048;
                 const int fw = f0 + wr * 128;
                 float4 b4[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) b4[i] = *reinterpret_cast<const float4 *>(bias_lds + fw + 16 * i + 4 * h);
-                const int wsw = (r16 & 7) << 4;
+                const int wrow = r16 & 7, wsw = wrow << 4;
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
+                    // the column's 16-bit values (bias, activation) once, then two 8-row passes through the scratch
+                    uint2 pk[8];
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const f32x4 a = acc[i][p];
@@ -551,19 +584,25 @@ __global__ void __launch_bounds__(512, 1) gemm256p_kernel(GemmArgs g) {
                         }
                         const uint16_t o[4] = {E::from_float(v01.x), E::from_float(v01.y), E::from_float(v23.x),
                                                E::from_float(v23.y)};
-                        uint2 pk;
-                        __builtin_memcpy(&pk, o, 8);
-                        *reinterpret_cast<uint2 *>(scratch + r16 * 256 + ((32 * i + 8 * h) ^ wsw)) = pk;
+                        __builtin_memcpy(&pk[i], o, 8);
                     }
 #pragma unroll
-                    for (int it = 0; it < 4; ++it) {
-                        const int c = it * 64 + lane, row = c >> 4, ch = c & 15;
-                        const uint4 v = *reinterpret_cast<const uint4 *>(scratch + row * 256 + ((ch ^ (row & 7)) << 4));
-                        const int t = t0 + wc * 64 + 16 * p + row;
-                        if (ABL & 8) {
-                            asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
-                        } else if (t < M) {
-                            *reinterpret_cast<uint4 *>(g.out16 + (size_t)t * g.ldo + fw + ch * 8) = v;
+                    for (int half = 0; half < 2; ++half) {
+                        if ((r16 >> 3) == half) {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i)
+                                *reinterpret_cast<uint2 *>(scratch + wrow * 256 + ((32 * i + 8 * h) ^ wsw)) = pk[i];
+                        }
+#pragma unroll
+                        for (int it = 0; it < 2; ++it) {
+                            const int c = it * 64 + lane, row = c >> 4, ch = c & 15;
+                            const uint4 v = *reinterpret_cast<const uint4 *>(scratch + row * 256 + ((ch ^ row) << 4));
+                            const int t = t0 + wc * 64 + 16 * p + 8 * half + row;
+                            if (ABL & 8) {
+                                asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+                            } else if (t < M) {
+                                *reinterpret_cast<uint4 *>(g.out16 + (size_t)t * g.ldo + fw + ch * 8) = v;
+                            }
                         }
                     }
                 }
@@ -580,10 +619,21 @@ __global__ void __launch_bounds__(512, 1) gemm256p_kernel(GemmArgs g) {
         }
         if (wr == 1) VM_BAR();
         if (!has_next) break;
+        {   // how many stores did this wave's epilogue leave in the pipe?  exact only for a full 16-bit tile
+            const int tm_done = tile / tiles_n;
+            const bool full = ((tm_done << 8) + 256 <= M) &&
+                              (EPI == EPI_STORE16 || EPI == EPI_GELU16 || EPI == EPI_QGELU16) && !(ABL & 24);
+            ep = full ? 1 : 2;
+        }
+        prestaged = do_prestage;
+        if (!prestaged) {  // single-K-tile GEMMs: no counted skipping, drain everything once
+            wait_vmcnt<0>();
+            ep = 0;
+        }
         zero_acc();
         tile = next_tile;
-        after_epi = true;
     }
+#undef VM_WAIT_EP
     if (wr == 0) VM_BAR();  // match wave row 1's extra barrier
 #undef VM_BAR
 #undef VM_LGKM0
@@ -689,7 +739,7 @@ int launch_epi(vm_ctx *ctx, const GemmArgs &g, hipStream_t st) {
     const bool use256 = (variant == 2 || variant == 3) ? big_ok : (variant == 1 ? false : (big_ok && tiles256 * 10 >= ctx->num_cus * 8));
 #ifdef VM_GEMM_ABLATE
     if (variant >= 1024 && DT == VM_F16) {  // persistent-kernel ablations: 1024 + 8 (no stores) / + 16 (no epilogue)
-        const size_t lds = 8 * HALF_BYTES + (size_t)g.N * 4;
+        const size_t lds = 8 * HALF_BYTES + (size_t)g.N * 4 + 16384;
         const int grid = tiles256 < ctx->num_cus ? tiles256 : ctx->num_cus;
         if (variant == 1024 + 8) {
             auto k = gemm256p_kernel<VM_F16, EPI, 8>;
@@ -718,14 +768,13 @@ int launch_epi(vm_ctx *ctx, const GemmArgs &g, hipStream_t st) {
         return VM_OK;
     }
 #endif
-    if (use256 && variant != 2) {
+    if (use256 && variant != 2 && g.N <= 4096) {
         auto kern = gemm256p_kernel<DT, EPI>;
         static bool attr_set_p = false;
-        if (g.N > 8192) return vm_fail(ctx, VM_ERR_UNSUPPORTED, "gemm: N=%d > 8192", g.N);
-        const size_t lds = 8 * HALF_BYTES + (size_t)g.N * 4;  // staging + bias table
+        const size_t lds = 8 * HALF_BYTES + (size_t)g.N * 4 + 16384;  // staging + bias table + epilogue scratch
         if (!attr_set_p) {
             VM_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            8 * HALF_BYTES + 8192 * 4));
+                                            163840));
             attr_set_p = true;
         }
         const int grid = tiles256 < ctx->num_cus ? tiles256 : ctx->num_cus;
