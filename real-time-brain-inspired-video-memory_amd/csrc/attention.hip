@@ -20,17 +20,113 @@ namespace {
 
 typedef short s4v __attribute__((__vector_size__(4 * sizeof(short))));
 typedef __attribute__((address_space(3))) s4v *lds_s4v_ptr;
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+typedef const __attribute__((address_space(1))) void *gbl_ptr_t;
 
-// NT = key tiles of 16 (13 for 197 tokens, 37 for 577).  EXACT: T > 16*(NT-1), so only the last tile has masked keys
-// and the mask is resolved at compile time for every other tile.
+// One 16-query tile against all keys of the (frame, head) staged in LDS: scores, softmax, P.V, context store.
 template <int DT, int NT, bool EXACT>
-__global__ void __launch_bounds__(256, (NT <= 13 ? 2 : 1))
-    attention_kernel(const uint16_t *__restrict__ qkv, uint16_t *__restrict__ ctx_out, int T, int heads) {
+__device__ __forceinline__ void attend_tile(const char *kl, const char *vl, typename vm_elem<DT>::vec8 qa,
+                                            typename vm_elem<DT>::vec8 qb, int T, int lane, bool qvalid,
+                                            uint16_t *dst_row) {
     using E = vm_elem<DT>;
     using vec8 = typename E::vec8;
     constexpr int NS = (NT + 1) / 2;  // 32-key steps of the PV product
+    const int r16 = lane & 15, h = lane >> 4;
+    const float scale_log2e = 0.125f * 1.44269504088896340736f;  // 1/sqrt(64) * log2(e)
+    // transposing-read lane constants: lane i of a 16-lane group addresses row q = i>>2, columns 4p.. (p = i&3)
+    const int tq = r16 >> 2, tp = r16 & 3;
+    // raw scores; key tiles that reach past T get their tail masked (block-uniform test)
+    f32x4 s[NT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+        const int key = kt * 16 + r16;
+        const vec8 k0 = *reinterpret_cast<const vec8 *>(kl + key * 128 + ((h ^ (key & 7)) << 4));
+        const vec8 k1 = *reinterpret_cast<const vec8 *>(kl + key * 128 + (((h + 4) ^ (key & 7)) << 4));
+        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+        a = E::mfma16(k0, qa, a);
+        a = E::mfma16(k1, qb, a);
+        if (EXACT ? (kt == NT - 1) : (kt * 16 + 16 > T)) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] = (kt * 16 + 4 * h + j < T) ? a[j] : -INFINITY;
+        }
+        mx = fmaxf(fmaxf(mx, fmaxf(a[0], a[1])), fmaxf(a[2], a[3]));
+        s[kt] = a;
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    // exp((s - max) / 8) = exp2(s * c - max * c): one fma + one v_exp per score
+    const float neg_mxc = -mx * scale_log2e;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 c2 = {scale_log2e, scale_log2e}, n2 = {neg_mxc, neg_mxc};
+    f32x2 sum2 = {0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+        // the fma and the running sum on 2-vectors (v_pk_fma_f32 / v_pk_add_f32); v_exp_f32 is scalar
+        f32x2 a01 = __builtin_elementwise_fma(f32x2{s[kt][0], s[kt][1]}, c2, n2);
+        f32x2 a23 = __builtin_elementwise_fma(f32x2{s[kt][2], s[kt][3]}, c2, n2);
+        a01 = f32x2{__builtin_amdgcn_exp2f(a01.x), __builtin_amdgcn_exp2f(a01.y)};
+        a23 = f32x2{__builtin_amdgcn_exp2f(a23.x), __builtin_amdgcn_exp2f(a23.y)};
+        sum2 += a01;
+        sum2 += a23;
+        s[kt] = f32x4{a01.x, a01.y, a23.x, a23.y};
+    }
+    float sum = sum2.x + sum2.y;
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < NS; ++ks) {
+        uint16_t pe[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            pe[j] = E::from_float(s[2 * ks][j]);
+            pe[4 + j] = (2 * ks + 1 < NT) ? E::from_float(s[2 * ks + 1][j]) : (uint16_t)0;
+        }
+        vec8 pf;
+        __builtin_memcpy(&pf, pe, 16);
+        const int key_lo = ks * 32 + 4 * h + tq, key_hi = key_lo + 16;  // (key & 7) is the same for both
+        const char *row_lo = vl + key_lo * 128 + (tp & 1) * 8;
+        const int sw = key_lo & 7;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const int coff = ((2 * dt + (tp >> 1)) ^ sw) << 4;
+            const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr)(row_lo + coff));
+            const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (lds_s4v_ptr)(row_lo + (2 * ks + 1 < NT ? 16 * 128 : 0) + coff));
+            typedef short s8v __attribute__((__vector_size__(8 * sizeof(short))));
+            const s8v av = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);  // register pair concatenation
+            o[dt] = E::mfma16(__builtin_bit_cast(vec8, av), pf, o[dt]);
+        }
+        (void)key_hi;
+    }
+    if (qvalid) {
+        uint16_t *dst = dst_row + 4 * h;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            uint16_t oe[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) oe[j] = E::from_float(o[dt][j] * inv);
+            uint2 pk;
+            __builtin_memcpy(&pk, oe, 8);
+            *reinterpret_cast<uint2 *>(dst + dt * 16) = pk;
+        }
+    }
+}
+
+// NT = key tiles of 16 (13 for 197 tokens, 37 for 577).  EXACT: T > 16*(NT-1), so only the last tile has masked keys
+// and the mask is resolved at compile time for every other tile.
+template <int DT, int NT, bool EXACT, int OCC>
+__global__ void __launch_bounds__(256, OCC)
+    attention_kernel(const uint16_t *__restrict__ qkv, uint16_t *__restrict__ ctx_out, int T, int heads) {
+    using E = vm_elem<DT>;
+    using vec8 = typename E::vec8;
     constexpr int KROWS = NT * 16;
-    constexpr int VROWS = NS * 32;
+    constexpr int VROWS = KROWS;             // an odd last 16-key half step re-reads valid rows against P = 0
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *kl = smem;                         // [KROWS][128 B]
     char *vl = smem + (size_t)KROWS * 128;   // [VROWS][128 B]
@@ -42,138 +138,148 @@ __global__ void __launch_bounds__(256, (NT <= 13 ? 2 : 1))
     const size_t ld = (size_t)3 * H;
     const uint16_t *base = qkv + (size_t)b * T * ld + head * 64;
 
-    // ---- stage K and V rows (16-byte chunks, swizzled; rows past T are zero) -------------------------------
-    // loads are issued in batches of 7 before their LDS writes so that each thread keeps 7 x 16 B in flight
+    // ---- stage K and V rows by LDS-DMA (global_load_lds_dwordx4: 1 KiB = 8 rows per wave instruction) -----------
+    // The swizzle is applied on the per-lane SOURCE chunk; rows past T re-read row T-1 (finite data: their scores
+    // are masked to -inf and their probabilities are exactly 0), so nothing has to be zero-filled.
+    auto load_q = [&](int qt, vec8 &q0, vec8 &q1) {
+        int qtok = qt * 16 + r16;
+        if (qtok > T - 1) qtok = T - 1;
+        const uint16_t *qp = base + (size_t)qtok * ld;
+        q0 = __builtin_bit_cast(vec8, *reinterpret_cast<const uint4 *>(qp + 8 * h));
+        q1 = __builtin_bit_cast(vec8, *reinterpret_cast<const uint4 *>(qp + 32 + 8 * h));
+    };
+    vec8 q0, q1;
+    load_q(wave, q0, q1);  // first query tile of this wave: in flight together with the K/V rows
     {
-        constexpr int TOTAL = (KROWS + VROWS) * 8;
-        constexpr int ITERS = (TOTAL + 255) / 256;
-        constexpr int BATCH = 7;
+        constexpr int GROUPS = (KROWS + VROWS) / 8;
+        const int srow = lane >> 3, scp = lane & 7;
 #pragma unroll
-        for (int it0 = 0; it0 < ITERS; it0 += BATCH) {
-            uint4 v[BATCH];
-#pragma unroll
-            for (int u = 0; u < BATCH; ++u) {
-                const int idx = tid + (it0 + u) * 256;
-                const bool is_v = idx >= KROWS * 8;
-                const int i2 = is_v ? idx - KROWS * 8 : idx;
-                const int key = i2 >> 3, c = i2 & 7;
-                v[u] = make_uint4(0, 0, 0, 0);
-                if (it0 + u < ITERS && idx < TOTAL && key < T)
-                    v[u] = *reinterpret_cast<const uint4 *>(base + (size_t)key * ld + (is_v ? 2 * H : H) + c * 8);
-            }
-#pragma unroll
-            for (int u = 0; u < BATCH; ++u) {
-                const int idx = tid + (it0 + u) * 256;
-                const bool is_v = idx >= KROWS * 8;
-                const int i2 = is_v ? idx - KROWS * 8 : idx;
-                const int key = i2 >> 3, c = i2 & 7;
-                if (it0 + u < ITERS && idx < TOTAL)
-                    *reinterpret_cast<uint4 *>((is_v ? vl : kl) + key * 128 + ((c ^ (key & 7)) << 4)) = v[u];
+        for (int gi = 0; gi < (GROUPS + 3) / 4; ++gi) {
+            const int grp = gi * 4 + wave;
+            if (grp < GROUPS) {
+                const int r = grp * 8 + srow;  // LDS row; K rows first, V rows behind them
+                const bool is_v = r >= KROWS;
+                int key = is_v ? r - KROWS : r;
+                if (key > T - 1) key = T - 1;
+                const uint16_t *src = base + (size_t)key * ld + (is_v ? 2 * H : H) + ((scp ^ (r & 7)) << 3);
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(smem + grp * 1024), 16, 0, 0);
             }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
 
-    const float scale_log2e = 0.125f * 1.44269504088896340736f;  // 1/sqrt(64) * log2(e)
-    // transposing-read lane constants: lane i of a 16-lane group addresses row q = i>>2, columns 4p.. (p = i&3)
-    const int tq = r16 >> 2, tp = r16 & 3;
-
     for (int qt = wave; qt < NT; qt += 4) {
-        int qtok = qt * 16 + r16;
+        const int qtok = qt * 16 + r16;
         const bool qvalid = qtok < T;
-        if (!qvalid) qtok = T - 1;
-        const uint16_t *qp = base + (size_t)qtok * ld;
-        const vec8 q0 = __builtin_bit_cast(vec8, *reinterpret_cast<const uint4 *>(qp + 8 * h));
-        const vec8 q1 = __builtin_bit_cast(vec8, *reinterpret_cast<const uint4 *>(qp + 32 + 8 * h));
+        const vec8 qa = q0, qb = q1;
+        if (qt + 4 < NT) load_q(qt + 4, q0, q1);  // next tile's queries: their latency hides behind this tile
 
-        // raw scores; key tiles that reach past T get their tail masked (block-uniform test)
-        f32x4 s[NT];
-        float mx = -INFINITY;
-#pragma unroll
-        for (int kt = 0; kt < NT; ++kt) {
-            const int key = kt * 16 + r16;
-            const vec8 k0 = *reinterpret_cast<const vec8 *>(kl + key * 128 + ((h ^ (key & 7)) << 4));
-            const vec8 k1 = *reinterpret_cast<const vec8 *>(kl + key * 128 + (((h + 4) ^ (key & 7)) << 4));
-            f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
-            a = E::mfma16(k0, q0, a);
-            a = E::mfma16(k1, q1, a);
-            if (EXACT ? (kt == NT - 1) : (kt * 16 + 16 > T)) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) a[j] = (kt * 16 + 4 * h + j < T) ? a[j] : -INFINITY;
-            }
-            mx = fmaxf(fmaxf(mx, fmaxf(a[0], a[1])), fmaxf(a[2], a[3]));
-            s[kt] = a;
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        // exp((s - max) / 8) = exp2(s * c - max * c): one fma + one v_exp per score
-        const float neg_mxc = -mx * scale_log2e;
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        const f32x2 c2 = {scale_log2e, scale_log2e}, n2 = {neg_mxc, neg_mxc};
-        f32x2 sum2 = {0.f, 0.f};
-#pragma unroll
-        for (int kt = 0; kt < NT; ++kt) {
-            // the fma and the running sum on 2-vectors (v_pk_fma_f32 / v_pk_add_f32); v_exp_f32 is scalar
-            f32x2 a01 = __builtin_elementwise_fma(f32x2{s[kt][0], s[kt][1]}, c2, n2);
-            f32x2 a23 = __builtin_elementwise_fma(f32x2{s[kt][2], s[kt][3]}, c2, n2);
-            a01 = f32x2{__builtin_amdgcn_exp2f(a01.x), __builtin_amdgcn_exp2f(a01.y)};
-            a23 = f32x2{__builtin_amdgcn_exp2f(a23.x), __builtin_amdgcn_exp2f(a23.y)};
-            sum2 += a01;
-            sum2 += a23;
-            s[kt] = f32x4{a01.x, a01.y, a23.x, a23.y};
-        }
-        float sum = sum2.x + sum2.y;
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
-        const float inv = 1.0f / sum;
+        attend_tile<DT, NT, EXACT>(kl, vl, qa, qb, T, lane, qvalid,
+                                   ctx_out + ((size_t)b * T + (qvalid ? qtok : 0)) * H + head * 64);
+    }
+}
 
-        f32x4 o[4];
+// Streaming variant for short sequences (two Q/K/V images fit in LDS: NT <= 13): one persistent workgroup per CU walks
+// (frame, head) items.  Eight waves compute item i out of one LDS image while a ninth wave, the loader, fills the other
+// image with item i+1 by LDS-DMA.  The plain kernel above alternates a pure load phase with a pure compute phase per
+// workgroup, and the co-resident workgroups of a CU fall into step, so its time is load + compute; here it is
+// max(load, compute).  One raw s_barrier per item; the compute waves issue no global loads at all (the queries come
+// through LDS too), so they never wait on the vector-memory counter and their context stores drain in the background.
+// (The loader is a wave of its own because vmcnt is per wave: the compiler guards every transposing LDS read with
+// vmcnt(0) while an LDS-DMA of the same wave is in flight, which would serialise the two.)
+template <int DT, int NT, bool EXACT>
+__global__ void __launch_bounds__(576, 1)
+    attention_stream_kernel(const uint16_t *__restrict__ qkv, uint16_t *__restrict__ ctx_out, int T, int heads,
+                            int items) {
+    using E = vm_elem<DT>;
+    using vec8 = typename E::vec8;
+    constexpr int ROWS = NT * 16;
+    constexpr int IMG = 3 * ROWS * 128;   // K rows, V rows, Q rows
+    constexpr int QT = (NT + 7) / 8;      // query tiles per compute wave
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H = heads * 64;
+    const size_t ld = (size_t)3 * H;
+    if (blockIdx.x >= items) return;
+
+    if (wave == 8) {  // ---- loader ---------------------------------------------------------------------------
+        // per-lane constants: a wave instruction covers 8 rows x 128 B; lane -> (row srow, stored chunk scp), and
+        // since every group starts at a multiple of 8 rows the source chunk (scp ^ row & 7) is fixed per lane
+        const int srow = lane >> 3, scp = lane & 7;
+        const unsigned ldb = (unsigned)ld * 2;                        // row pitch in bytes
+        const unsigned lane_off = (unsigned)((scp ^ srow) << 4);
+        const int tmax = T - 1;
+        int buf = 0;
+        for (int item = blockIdx.x; item < items; item += gridDim.x, buf ^= 1) {
+            const int b = item / heads, head = item - b * heads;
+            const char *base = reinterpret_cast<const char *>(qkv + (size_t)b * T * ld + head * 64);  // wave-uniform
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int part = 0; part < 3; ++part) {  // LDS image order K, V, Q; qkv row order Q, K, V
+                const char *pbase = base + (part == 2 ? 0 : (part + 1) * H * 2);
 #pragma unroll
-        for (int ks = 0; ks < NS; ++ks) {
-            uint16_t pe[8];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                pe[j] = E::from_float(s[2 * ks][j]);
-                pe[4 + j] = (2 * ks + 1 < NT) ? E::from_float(s[2 * ks + 1][j]) : (uint16_t)0;
+                for (int g = 0; g < ROWS / 8; ++g) {
+                    int key = g * 8 + srow;
+                    if (!EXACT || g * 8 + 7 >= 16 * (NT - 1)) key = key > tmax ? tmax : key;  // groups that can pass T
+                    const unsigned off = (unsigned)key * ldb + lane_off;
+                    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(pbase + off),
+                                                     (lds_ptr_t)(smem + buf * IMG + (part * (ROWS / 8) + g) * 1024), 16,
+                                                     0, 0);
+                    // at most 28 KiB of this wave's fills queued in the CU's in-order memory pipe: the compute
+                    // waves' context stores enter the same queue and must not wait behind a whole image
+                    if ((g & 3) == 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+                }
             }
-            vec8 pf;
-            __builtin_memcpy(&pf, pe, 16);
-            const int key_lo = ks * 32 + 4 * h + tq, key_hi = key_lo + 16;  // (key & 7) is the same for both
-            const char *row_lo = vl + key_lo * 128 + (tp & 1) * 8;
-            const int sw = key_lo & 7;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const int coff = ((2 * dt + (tp >> 1)) ^ sw) << 4;
-                const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr)(row_lo + coff));
-                const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr)(row_lo + 16 * 128 + coff));
-                typedef short s8v __attribute__((__vector_size__(8 * sizeof(short))));
-                const s8v av = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);  // register pair concatenation
-                o[dt] = E::mfma16(__builtin_bit_cast(vec8, av), pf, o[dt]);
-            }
-            (void)key_hi;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");
         }
-        if (qvalid) {
-            uint16_t *dst = ctx_out + ((size_t)b * T + qtok) * H + head * 64 + 4 * h;
+        return;
+    }
+
+    // ---- compute waves ----------------------------------------------------------------------------------------
+    const int r16 = lane & 15, h = lane >> 4;
+    int buf = 0;
+    for (int item = blockIdx.x; item < items; item += gridDim.x, buf ^= 1) {
+        asm volatile("s_barrier" ::: "memory");  // the loader has landed this item's image
+        const char *kl = smem + buf * IMG, *vl = kl + ROWS * 128, *ql = vl + ROWS * 128;
+        const int b = item / heads, head = item - b * heads;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                uint16_t oe[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) oe[j] = E::from_float(o[dt][j] * inv);
-                uint2 pk;
-                __builtin_memcpy(&pk, oe, 8);
-                *reinterpret_cast<uint2 *>(dst + dt * 16) = pk;
+        for (int u = 0; u < QT; ++u) {
+            const int qt = wave + 8 * u;
+            if (qt < NT) {
+                const int qtok = qt * 16 + r16;
+                const bool qvalid = qtok < T;
+                const vec8 qa = *reinterpret_cast<const vec8 *>(ql + qtok * 128 + ((h ^ (qtok & 7)) << 4));
+                const vec8 qb = *reinterpret_cast<const vec8 *>(ql + qtok * 128 + (((h + 4) ^ (qtok & 7)) << 4));
+                attend_tile<DT, NT, EXACT>(kl, vl, qa, qb, T, lane, qvalid,
+                                           ctx_out + ((size_t)b * T + (qvalid ? qtok : 0)) * H + head * 64);
             }
         }
     }
 }
 
 template <int DT, int NT, bool EXACT>
+int launch_stream(vm_ctx *ctx, const uint16_t *qkv, uint16_t *out, int B, int T, int heads, hipStream_t st) {
+    const size_t lds = (size_t)NT * 16 * 128 * 6;
+    auto kern = attention_stream_kernel<DT, NT, EXACT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        VM_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int items = B * heads;
+    const int grid = items < ctx->num_cus ? items : ctx->num_cus;
+    vm_prof_scope prof(ctx, VM_PROF_ATTENTION, st);
+    kern<<<grid, 576, lds, st>>>(qkv, out, T, heads, items);
+    VM_LAUNCH_CHECK(ctx);
+    return VM_OK;
+}
+
+template <int DT, int NT, bool EXACT, int OCC = (NT <= 13 ? 2 : 1)>
 int launch(vm_ctx *ctx, const uint16_t *qkv, uint16_t *out, int B, int T, int heads, hipStream_t st) {
-    constexpr int NS = (NT + 1) / 2;
-    const size_t lds = (size_t)NT * 16 * 128 + (size_t)NS * 32 * 128;
-    auto kern = attention_kernel<DT, NT, EXACT>;
+    const size_t lds = (size_t)NT * 16 * 128 * 2;
+    auto kern = attention_kernel<DT, NT, EXACT, OCC>;
     static bool attr_set = false;
     if (!attr_set) {
         VM_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -188,7 +294,11 @@ int launch(vm_ctx *ctx, const uint16_t *qkv, uint16_t *out, int B, int T, int he
 template <int DT>
 int dispatch(vm_ctx *ctx, const uint16_t *qkv, uint16_t *out, int B, int T, int heads, hipStream_t st) {
     const int nt = (T + 15) / 16;
-    if (nt == 13) return launch<DT, 13, true>(ctx, qkv, out, B, T, heads, st);   // ViT-B/16-224: 197 tokens
+    if (nt == 13) {  // ViT-B/16-224: 197 tokens
+        static const bool plain = getenv("VIDMEM_ATT_PLAIN") != nullptr;  // developer A/B switch
+        return plain ? launch<DT, 13, true, 2>(ctx, qkv, out, B, T, heads, st)
+                     : launch_stream<DT, 13, true>(ctx, qkv, out, B, T, heads, st);
+    }
     if (nt == 37) return launch<DT, 37, true>(ctx, qkv, out, B, T, heads, st);   // CLIP-L/14-336: 577 tokens
     if (nt <= 2) return launch<DT, 2, false>(ctx, qkv, out, B, T, heads, st);
     if (nt <= 5) return launch<DT, 5, false>(ctx, qkv, out, B, T, heads, st);
