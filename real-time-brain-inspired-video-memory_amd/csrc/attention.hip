@@ -135,8 +135,9 @@ __global__ void __launch_bounds__(256, OCC)
     const int r16 = lane & 15, h = lane >> 4;
     const int b = blockIdx.x / heads, head = blockIdx.x - b * heads;
     const int H = heads * 64;
-    const size_t ld = (size_t)3 * H;
-    const uint16_t *base = qkv + (size_t)b * T * ld + head * 64;
+    // head-major input: block (part * heads + head) is a contiguous [M, 64] matrix, part 0 = q, 1 = k, 2 = v
+    const size_t M = (size_t)(gridDim.x / heads) * T;
+    auto block = [&](int part) { return qkv + ((size_t)(part * heads + head) * M + (size_t)b * T) * 64; };
 
     // ---- stage K and V rows by LDS-DMA (global_load_lds_dwordx4: 1 KiB = 8 rows per wave instruction) -----------
     // The swizzle is applied on the per-lane SOURCE chunk; rows past T re-read row T-1 (finite data: their scores
@@ -144,7 +145,7 @@ __global__ void __launch_bounds__(256, OCC)
     auto load_q = [&](int qt, vec8 &q0, vec8 &q1) {
         int qtok = qt * 16 + r16;
         if (qtok > T - 1) qtok = T - 1;
-        const uint16_t *qp = base + (size_t)qtok * ld;
+        const uint16_t *qp = block(0) + (size_t)qtok * 64;
         q0 = __builtin_bit_cast(vec8, *reinterpret_cast<const uint4 *>(qp + 8 * h));
         q1 = __builtin_bit_cast(vec8, *reinterpret_cast<const uint4 *>(qp + 32 + 8 * h));
     };
@@ -161,7 +162,7 @@ __global__ void __launch_bounds__(256, OCC)
                 const bool is_v = r >= KROWS;
                 int key = is_v ? r - KROWS : r;
                 if (key > T - 1) key = T - 1;
-                const uint16_t *src = base + (size_t)key * ld + (is_v ? 2 * H : H) + ((scp ^ (r & 7)) << 3);
+                const uint16_t *src = block(is_v ? 2 : 1) + (size_t)key * 64 + ((scp ^ (r & 7)) << 3);
                 __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(smem + grp * 1024), 16, 0, 0);
             }
         }
@@ -201,28 +202,27 @@ __global__ void __launch_bounds__(576, 1)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = heads * 64;
-    const size_t ld = (size_t)3 * H;
     if (blockIdx.x >= items) return;
 
     if (wave == 8) {  // ---- loader ---------------------------------------------------------------------------
         // per-lane constants: a wave instruction covers 8 rows x 128 B; lane -> (row srow, stored chunk scp), and
         // since every group starts at a multiple of 8 rows the source chunk (scp ^ row & 7) is fixed per lane
         const int srow = lane >> 3, scp = lane & 7;
-        const unsigned ldb = (unsigned)ld * 2;                        // row pitch in bytes
         const unsigned lane_off = (unsigned)((scp ^ srow) << 4);
+        const size_t M = (size_t)(items / heads) * T;  // rows of each head-major [M, 64] block
         const int tmax = T - 1;
         int buf = 0;
         for (int item = blockIdx.x; item < items; item += gridDim.x, buf ^= 1) {
             const int b = item / heads, head = item - b * heads;
-            const char *base = reinterpret_cast<const char *>(qkv + (size_t)b * T * ld + head * 64);  // wave-uniform
 #pragma unroll
-            for (int part = 0; part < 3; ++part) {  // LDS image order K, V, Q; qkv row order Q, K, V
-                const char *pbase = base + (part == 2 ? 0 : (part + 1) * H * 2);
+            for (int part = 0; part < 3; ++part) {  // LDS image order K, V, Q; qkv block order q, k, v
+                const char *pbase = reinterpret_cast<const char *>(
+                    qkv + ((size_t)((part == 2 ? 0 : part + 1) * heads + head) * M + (size_t)b * T) * 64);  // uniform
 #pragma unroll
                 for (int g = 0; g < ROWS / 8; ++g) {
                     int key = g * 8 + srow;
                     if (!EXACT || g * 8 + 7 >= 16 * (NT - 1)) key = key > tmax ? tmax : key;  // groups that can pass T
-                    const unsigned off = (unsigned)key * ldb + lane_off;
+                    const unsigned off = (unsigned)key * 128 + lane_off;  // 8 rows = one contiguous KiB
                     __builtin_amdgcn_global_load_lds((gbl_ptr_t)(pbase + off),
                                                      (lds_ptr_t)(smem + buf * IMG + (part * (ROWS / 8) + g) * 1024), 16,
                                                      0, 0);
@@ -295,9 +295,7 @@ template <int DT>
 int dispatch(vm_ctx *ctx, const uint16_t *qkv, uint16_t *out, int B, int T, int heads, hipStream_t st) {
     const int nt = (T + 15) / 16;
     if (nt == 13) {  // ViT-B/16-224: 197 tokens
-        static const bool plain = getenv("VIDMEM_ATT_PLAIN") != nullptr;  // developer A/B switch
-        return plain ? launch<DT, 13, true, 2>(ctx, qkv, out, B, T, heads, st)
-                     : launch_stream<DT, 13, true>(ctx, qkv, out, B, T, heads, st);
+        return launch_stream<DT, 13, true>(ctx, qkv, out, B, T, heads, st);
     }
     if (nt == 37) return launch<DT, 37, true>(ctx, qkv, out, B, T, heads, st);   // CLIP-L/14-336: 577 tokens
     if (nt <= 2) return launch<DT, 2, false>(ctx, qkv, out, B, T, heads, st);

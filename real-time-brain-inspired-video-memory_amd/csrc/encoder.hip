@@ -489,11 +489,12 @@ extern "C" int vm_encode(vm_encoder *e, const void *patches, int B, void *out_em
         const int nb = B - b0 < mb ? B - b0 : mb;
         const int rows = nb * T;
         GemmArgs g;
+        int g_head_major = 0;
         auto gemm16 = [&](const uint16_t *X, int ldx, const uint16_t *W, const float *bias, uint16_t *out, int M, int N,
                           int K, int epi, int cat) {
             memset(&g, 0, sizeof(g));
             g.X = X; g.W = W; g.bias = bias; g.out16 = out;
-            g.M = M; g.N = N; g.K = K; g.ldx = ldx; g.ldo = N; g.prof_cat = cat;
+            g.M = M; g.N = N; g.K = K; g.ldx = ldx; g.ldo = N; g.prof_cat = cat; g.head_major = g_head_major;
             return vm_gemm(ctx, dt, g, epi, st);
         };
         // patch embedding: [nb*P, patch_k] x [H, patch_k]^T (+bias) -> 16-bit rows; then x32 = rows + pos (+cls) [+pre-LN]
@@ -505,7 +506,10 @@ extern "C" int vm_encode(vm_encoder *e, const void *patches, int B, void *out_em
         for (int l = 0; l < d.layers; ++l) {
             const LayerW &w = e->layers[l];
             if ((rc = vm_resid_layernorm(ctx, dt, ws.x32, delta, w.ln1_g, w.ln1_b, d.ln_eps, ws.a16, rows, H, st)) != VM_OK) return rc;
-            if ((rc = gemm16(ws.a16, H, w.qkv_w, w.qkv_b, ws.qkv16, rows, 3 * H, H, EPI_STORE16, VM_PROF_GEMM_QKV)) != VM_OK) return rc;
+            g_head_major = 1;  // q/k/v of one head as contiguous [rows, 64] blocks: attention streams whole KiB
+            rc = gemm16(ws.a16, H, w.qkv_w, w.qkv_b, ws.qkv16, rows, 3 * H, H, EPI_STORE16, VM_PROF_GEMM_QKV);
+            g_head_major = 0;
+            if (rc != VM_OK) return rc;
             if ((rc = vm_attention(ctx, dt, ws.qkv16, ws.a16, nb, T, d.heads, st)) != VM_OK) return rc;
             if ((rc = gemm16(ws.a16, H, w.proj_w, w.proj_b, ws.d16, rows, H, H, EPI_STORE16, VM_PROF_GEMM_RESID)) != VM_OK) return rc;
             if ((rc = vm_resid_layernorm(ctx, dt, ws.x32, ws.d16, w.ln2_g, w.ln2_b, d.ln_eps, ws.a16, rows, H, st)) != VM_OK) return rc;

@@ -79,6 +79,12 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
     return o;
 }
 
+// Element index of out16[t, f]: row-major [M, ldo], or head-major [N/64][M][64] (each 64-feature head a contiguous
+// [M, 64] block: what the attention kernel streams; see vm_kernels.h).
+__device__ __forceinline__ size_t out16_index(const GemmArgs &g, int t, int f) {
+    return g.head_major ? ((((size_t)(f >> 6) * g.M + t) << 6) | (f & 63)) : (size_t)t * g.ldo + f;
+}
+
 // XCD-aware renumbering (bijective for any grid size): ids that share (blockIdx % 8) become neighbours.
 __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
     const int xcd = orig & 7, qd = nwg >> 3, rm = nwg & 7;
@@ -95,7 +101,6 @@ __device__ __forceinline__ void epilogue_row(const GemmArgs &g, const f32x4 (&a)
 #pragma unroll
     for (int i = 0; i < NI; ++i) b4[i] = *reinterpret_cast<const float4 *>(g.bias + fbase + 16 * i);
     if (EPI == EPI_STORE16 || EPI == EPI_GELU16 || EPI == EPI_QGELU16) {
-        uint16_t *orow = g.out16 + (size_t)t * g.ldo + fbase;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             float v[4] = {a[i][0] + b4[i].x, a[i][1] + b4[i].y, a[i][2] + b4[i].z, a[i][3] + b4[i].w};
@@ -109,7 +114,7 @@ __device__ __forceinline__ void epilogue_row(const GemmArgs &g, const f32x4 (&a)
             }
             uint2 pk;
             __builtin_memcpy(&pk, o, 8);
-            *reinterpret_cast<uint2 *>(orow + 16 * i) = pk;
+            *reinterpret_cast<uint2 *>(g.out16 + out16_index(g, t, fbase + 16 * i)) = pk;
         }
     } else if (EPI == EPI_RESID32) {
         float *orow = g.out32 + (size_t)t * g.ldo + fbase;
@@ -601,7 +606,7 @@ __global__ void __launch_bounds__(512, 1) gemm256p_kernel(GemmArgs g) {
                             if (ABL & 8) {
                                 asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
                             } else if (t < M) {
-                                *reinterpret_cast<uint4 *>(g.out16 + (size_t)t * g.ldo + fw + ch * 8) = v;
+                                *reinterpret_cast<uint4 *>(g.out16 + out16_index(g, t, fw + ch * 8)) = v;
                             }
                         }
                     }

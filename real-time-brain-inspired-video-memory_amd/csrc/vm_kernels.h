@@ -21,11 +21,13 @@ struct GemmArgs {
     int ldx, ldo;
     int P, T;           // EPI_PATCH only: patches per frame, tokens per frame
     int prof_cat;       // vm_prof_cat of this launch (bench.py's per-kernel breakdown)
+    int head_major;     // 16-bit epilogues: out16 is [N/64][M][64] (per-head contiguous blocks) instead of [M, ldo]
 };
 
 int vm_gemm(vm_ctx *ctx, int dtype, const GemmArgs &g, int epi, hipStream_t st);
 
-// qkv [B*T, 3H] 16-bit (q | k | v, head h at columns h*64) -> ctx [B*T, H] 16-bit; head dim 64.
+// qkv HEAD-MAJOR 16-bit [3*heads][B*T][64] (block index = {q,k,v} * heads + head; GemmArgs::head_major) ->
+// ctx [B*T, H] 16-bit row-major; head dim 64.
 int vm_attention(vm_ctx *ctx, int dtype, const uint16_t *qkv, uint16_t *ctx_out, int B, int T, int heads,
                  hipStream_t st);
 
