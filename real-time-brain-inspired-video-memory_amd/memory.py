@@ -158,16 +158,22 @@ class EmbeddingMemory:
     # ---- persistence: the reference's only durable store is the `embedding` list property
     # (src/components/neo4j_handler.py:229-242) and the export JSON (src/components/graph_exporter.py:61-67);
     # here: raw 16-bit rows in row-id order + the host id / meta tables, one .npz ------------------------------
-    def snapshot(self, path: str) -> None:
-        import json
+    def rows_host(self):
+        """(first_row_id, uint16 [n, D]): the searchable rows as raw 16-bit patterns in row-id order (host copy)."""
         import numpy as np
         total, n = len(self), self.searchable
         phys = self.rows_tensor().view(torch.int16)
         if self.ring and total > self.capacity:  # oldest row sits at slot total % capacity
             head = total % self.capacity
             phys = torch.cat([phys[head:], phys[:head]])
-        base = total - n
-        np.savez(path, rows=phys.cpu().numpy().view(np.uint16), dtype=self.dtype_name, dim=self.dim,
+        return total - n, phys.cpu().numpy().view(np.uint16)
+
+    def snapshot(self, path: str) -> None:
+        import json
+        import numpy as np
+        base, rows = self.rows_host()
+        total = base + rows.shape[0]
+        np.savez(path, rows=rows, dtype=self.dtype_name, dim=self.dim,
                  first_row_id=base, graph_uuid=self.graph_uuid or "",
                  ids=json.dumps(self.ids[base:total]), meta=json.dumps(self.meta[base:total]))
 
