@@ -115,7 +115,9 @@ def main():
     retriever = ShardedRetriever(memory, rank, world)
 
     # synthetic frames resident in HBM: a pool of distinct uint8 frames, cycled through the steps
-    pool_steps = 4
+    # (distinct frames for every step up to 32 steps: re-embedding a frame plants exact duplicates in the memory, and
+    # enough exact ties make a query uncertifiable on the fast path)
+    pool_steps = min(32, args.warmup + args.steps + 1)
     gf = torch.Generator(device=dev).manual_seed(1234 + rank)
     frame_pool = torch.randint(0, 256, (pool_steps, F, 224, 224, 3), generator=gf, device=dev, dtype=torch.uint8)
 
@@ -301,10 +303,23 @@ def main():
             e1.synchronize()
             lat.append(e0.elapsed_time(e1))
         lat = sorted(lat[10:])
+        # same chunk arriving in HOST memory: frames already in a pinned slot (where a decoder would
+        # write them), timed from the start of the H2D copy to the end of the replay, host clock
+        lat_h = []
+        for i in range(30):
+            view = sess.stager.next_slot()
+            torch.from_numpy(view).random_(0, 256)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            sess.push_staged(sess.stager.commit(16))
+            sess.stream.synchronize()
+            lat_h.append((time.perf_counter() - t0) * 1e3)
+        lat_h = sorted(lat_h[5:])
         out["streaming"] = {
             "workload": f"chunk of 16 x 1080p uint8 frames -> preprocess + ViT-B/16 fp16 + top-{k} over a rolling "
                         f"{Ms}-row x {D} ring + append, one hipGraph replay per chunk",
             "p50_ms": lat[len(lat) // 2], "p99_ms": lat[min(len(lat) - 1, int(len(lat) * 0.99))], "max_ms": lat[-1],
+            "p50_ms_from_pinned_host": lat_h[len(lat_h) // 2], "p99_ms_from_pinned_host": lat_h[-1],
             "budget_ms": 33.0, "replays": len(lat), "uncertified_queries": int(ring._uncert.item()),
         }
         del sess, chunk

@@ -118,6 +118,11 @@ int64_t vm_memory_size(const vm_memory *mem);  /* rows appended so far (host mir
 int64_t vm_memory_capacity(const vm_memory *mem);
 int vm_memory_dim(const vm_memory *mem);
 int vm_memory_reset(vm_memory *mem, void *stream);
+/* Re-read the DEVICE row counter into the host mirror and return it (negative = vm_status).  Needed after hipGraph
+ * replays of vm_memory_append (they advance only the device counter) and after a graph CAPTURE of it (which advanced
+ * only the host mirror).  Synchronises `stream`; not capturable.  The reference has no counterpart (its store is a
+ * database, src/components/neo4j_handler.py:229-242); this is the price of the capturable append. */
+int64_t vm_memory_sync(vm_memory *mem, void *stream);
 const void *vm_memory_rows(const vm_memory *mem); /* device pointer to the [capacity, D] row store          */
 
 /* ---- cosine top-k over the memory ---------------------------------------------------------------------

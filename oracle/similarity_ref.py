@@ -130,6 +130,29 @@ def post_compress_ref(
     return kept[:top_k]
 
 
+def true_chunk_rankings_ref(chunks, true_chunks):
+    """retriever_hybrid.py:173-190 / :247-262: 1-based rank of the first candidate whose id's last ``_`` field parses
+    to each true-chunk index; None when none does."""
+    rankings = {}
+    for idx in true_chunks:
+        rankings[idx] = None
+    for pos, c in enumerate(chunks, start=1):
+        try:
+            last_part = str(c.get("id")).split("_")[-1]
+            parsed_idx = int(last_part)
+        except Exception:
+            parsed_idx = None
+        if parsed_idx is not None and parsed_idx in rankings and rankings[parsed_idx] is None:
+            rankings[parsed_idx] = pos
+    return rankings
+
+
+def fuse_result_chunks_ref(chunk_results, traversal_chunks, top_k_chunks):
+    """retriever_hybrid.py:241-244: concatenation, then ``[:top_k_chunks]``."""
+    result_chunks = (chunk_results or []) + (traversal_chunks or [])
+    return result_chunks[:top_k_chunks]
+
+
 # --------------------------------------------------------------------------------------------------------------
 # numpy restatement with the SAME arithmetic (sequential fp64 sums) for mid-size cases
 # --------------------------------------------------------------------------------------------------------------

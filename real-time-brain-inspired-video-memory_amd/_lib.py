@@ -26,7 +26,7 @@ SYMBOLS = [
     "vm_encoder_create", "vm_encoder_destroy", "vm_encoder_tokens", "vm_encoder_patch_k", "vm_encoder_out_dim",
     "vm_encode_workspace_bytes", "vm_encode",
     "vm_memory_create", "vm_memory_destroy", "vm_memory_append", "vm_memory_size", "vm_memory_capacity",
-    "vm_memory_dim", "vm_memory_reset", "vm_memory_rows",
+    "vm_memory_dim", "vm_memory_reset", "vm_memory_sync", "vm_memory_rows",
     "vm_topk_workspace_bytes", "vm_topk_cosine", "vm_topk_exact_workspace_bytes", "vm_topk_cosine_exact",
     "vm_cosine_exact", "vm_topk_merge", "vm_profile_enable", "vm_profile_read", "vm_profile_mask",
 ]
@@ -81,6 +81,7 @@ def lib() -> C.CDLL:
         "vm_memory_capacity": (i64, [vp]),
         "vm_memory_dim": (i32, [vp]),
         "vm_memory_reset": (i32, [vp, vp]),
+        "vm_memory_sync": (i64, [vp, vp]),
         "vm_memory_rows": (vp, [vp]),
         "vm_topk_workspace_bytes": (sz, [vp, i32, i32]),
         "vm_topk_cosine": (i32, [vp, vp, i32, i32, i32, f64, i32, i64, i64, vp, vp, vp, vp, sz, vp]),

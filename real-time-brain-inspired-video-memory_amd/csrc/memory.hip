@@ -116,6 +116,15 @@ extern "C" int64_t vm_memory_capacity(const vm_memory *m) { return m ? m->cap : 
 extern "C" int vm_memory_dim(const vm_memory *m) { return m ? m->D : 0; }
 extern "C" const void *vm_memory_rows(const vm_memory *m) { return m ? m->rows : nullptr; }
 
+extern "C" int64_t vm_memory_sync(vm_memory *m, void *stream) {
+    if (!m) return VM_ERR_INVALID;
+    int64_t total = 0;
+    VM_HIP(m->ctx, hipMemcpyAsync(&total, m->d_total, sizeof(total), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    VM_HIP(m->ctx, hipStreamSynchronize((hipStream_t)stream));
+    m->h_total = total;
+    return total;
+}
+
 extern "C" int vm_memory_reset(vm_memory *m, void *stream) {
     if (!m) return VM_ERR_INVALID;
     VM_HIP(m->ctx, hipMemsetAsync(m->d_total, 0, 64, (hipStream_t)stream));

@@ -85,18 +85,33 @@ def chunk_plan(fps: float, total_frames: int, chunk_size_seconds: float, frames_
 
 
 class FrameEmbeddingExtractor:
-    def __init__(self, config: Any, encoder: FrameEncoder, memory: EmbeddingMemory, top_k: int = 5):
+    def __init__(self, config: Any, encoder: FrameEncoder, memory: EmbeddingMemory, top_k: int = 5,
+                 stager_factory=None):
         self.config = config
         self.encoder = encoder
         self.memory = memory
         self.top_k = top_k
         self.timings: List[Tuple[str, float]] = []
+        self._stager = None
+        self._stager_factory = stager_factory  # (frames, H, W, device) -> ingest.FrameStager-like; tests inject a host one
 
-    def _prepare(self, frames: List[np.ndarray]) -> torch.Tensor:
-        """List of BGR frames -> one uint8 device tensor.  Frames taller than 720 rows are downscaled on the GPU by
-        the preprocess kernel's own bilinear resize (the reference's cv2.resize to 720 rows, :114-116, only exists to
-        shrink the HTTP payload; the encoder input is 224/336 either way)."""
-        return torch.from_numpy(np.ascontiguousarray(np.stack(frames))).to(self.encoder.device)
+    def _read_chunk(self, src, indices) -> List[np.ndarray]:
+        """The reference's per-chunk frame pick (:107-111): unreadable frames are dropped.  Frames taller than 720
+        rows are NOT downscaled on the host: the preprocess kernel's own bilinear resize takes them to the encoder
+        input in one pass (the reference's cv2.resize to 720 rows, :114-116, only shrinks the HTTP payload)."""
+        return [f for f in (src.read(i) for i in indices) if f is not None]
+
+    def _stage(self, frames: List[np.ndarray]):
+        """Start the H2D copy of a chunk (ingest.FrameStager: pinned slot + copy stream); the stager is sized on the
+        first chunk and rebuilt if the frame size changes."""
+        h, w = frames[0].shape[:2]
+        cap = max(len(frames), int(self.config.video.frames_per_chunk))
+        if self._stager is None or self._stager.shape[1:3] != (h, w) or self._stager.shape[0] < len(frames):
+            factory = self._stager_factory
+            if factory is None:
+                from .ingest import FrameStager as factory
+            self._stager = factory(cap, h, w, self.encoder.device.index or 0)
+        return self._stager.stage(frames)
 
     async def process_video(self, video_path: str, output_path: str) -> str:
         run_id = str(uuid.uuid4())
@@ -106,27 +121,41 @@ class FrameEmbeddingExtractor:
             total_chunks, plan = chunk_plan(fps, total_frames, self.config.video.chunk_size_seconds,
                                             self.config.video.frames_per_chunk)
             results = []
-            for chunk_idx, start, end, indices, time_str in plan:
-                frames = [f for f in (src.read(i) for i in indices) if f is not None]
-                if not frames:
-                    continue
+
+            def read_and_stage(pi):
+                """Host side of chunk pi: frame reads + pinned staging + start of the H2D copy (None: no frames)."""
+                if pi >= len(plan):
+                    return None
+                frames = self._read_chunk(src, plan[pi][3])
+                return (len(frames), self._stage(frames)) if frames else None
+
+            staged = read_and_stage(0)
+            for pi, (chunk_idx, start, end, indices, time_str) in enumerate(plan):
                 chunk_start = time.perf_counter()
-                emb = self.encoder.embed_frames(self._prepare(frames))
+                current, emb = staged, None
+                if current is not None:
+                    nframes, ticket = current
+                    emb = self.encoder.embed_frames(self._stager.get(ticket))   # asynchronous launches
+                    self._stager.done(ticket)
+                # while the GPU encodes chunk pi, the host reads chunk pi+1 and its frames cross PCIe
+                staged = read_and_stage(pi + 1)
+                if emb is None:
+                    continue
                 similar = []
                 if self.memory.searchable and self.top_k > 0:
                     scores, rows = self.memory.topk(emb, self.top_k)
                     for s_row, r_row in zip(scores.cpu().tolist(), rows.cpu().tolist()):
                         similar.append([(self.memory.id_of(r), float(s)) for s, r in zip(s_row, r_row) if r >= 0])
-                ids = [f"{run_id}_{chunk_idx}_{i}" for i in range(len(frames))]  # pre_llm_injector.py:91 id scheme
-                first = self.memory.append(emb, ids=ids, meta=[{"time": time_str, "content": None}] * len(frames))
+                ids = [f"{run_id}_{chunk_idx}_{i}" for i in range(nframes)]  # pre_llm_injector.py:91 id scheme
+                first = self.memory.append(emb, ids=ids, meta=[{"time": time_str, "content": None}] * nframes)
                 torch.cuda.synchronize(self.encoder.device)
                 chunk_time = time.perf_counter() - chunk_start
                 results.append({
                     "time": time_str,
-                    "content": f"[{len(frames)} frame embeddings]",
+                    "content": f"[{nframes} frame embeddings]",
                     "chunk_idx": chunk_idx,
                     "processing_time": chunk_time,
-                    "embedding_rows": list(range(first, first + len(frames))),
+                    "embedding_rows": list(range(first, first + nframes)),
                     "similar": similar,
                 })
                 self.timings.append((f"chunk_{chunk_idx}", chunk_time))

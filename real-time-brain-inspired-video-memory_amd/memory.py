@@ -89,6 +89,22 @@ class EmbeddingMemory:
         self.meta.extend(list(meta) if meta is not None else [None] * B)
         return int(first.value)
 
+    def sync(self) -> int:
+        """Bring the host mirror (row count, id / meta tables) in line with the device counter: call after hipGraph
+        replays (streaming.StreamingSession) before eager appends, exhaustive searches or snapshots.  Rows appended
+        by replays get ``None`` ids; a captured-but-never-run append is dropped."""
+        total = int(self.L.vm_memory_sync(self.handle, _lib.current_stream_ptr()))
+        if total < 0:
+            self.ctx.check(total)
+        del self.ids[total:], self.meta[total:]
+        self.ids.extend([None] * (total - len(self.ids)))
+        self.meta.extend([None] * (total - len(self.meta)))
+        return total
+
+    def prepare_topk(self, Q: int, k: int) -> None:
+        """Size the top-k workspace for (Q, k) now, so a later graph capture allocates nothing."""
+        self._workspace(int(self.L.vm_topk_workspace_bytes(self.handle, int(Q), int(k))))
+
     def reset(self):
         self.ctx.check(self.L.vm_memory_reset(self.handle, _lib.current_stream_ptr()))
         self.ids.clear()

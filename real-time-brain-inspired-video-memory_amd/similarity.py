@@ -126,10 +126,21 @@ class HipVectorSearch:
                     owners.append(chunk)
             if not segments:
                 return []
-            seg_emb = [await self.embedder.aembed_query(s) for s in segments]
+            # segment embeds: one failure drops that segment only (retriever_hybrid.py:505-507)
+            seg_emb, keep = [], []
+            for i, seg in enumerate(segments):
+                try:
+                    seg_emb.append(await self.embedder.aembed_query(seg))
+                    keep.append(i)
+                except Exception as e:
+                    logger.debug("Failed to embed segment: %s", e)
+            if not seg_emb:
+                return []
+            # ONE [1, D] x [S, D] exact-cosine launch for all segments of all hits (the reference scores them one
+            # by one in Python, :497); filter >= threshold in encounter order, then [:top_k] (:499-510)
             sims = self.memory.cosine_exact([query_embedding], seg_emb)[0].cpu().tolist()
-            kept = [{**owners[i], "content": segments[i], "compression_score": float(sims[i])}
-                    for i in range(len(segments)) if sims[i] >= self.config.compression_threshold]
+            kept = [{**owners[i], "content": segments[i], "compression_score": float(sim)}
+                    for i, sim in zip(keep, sims) if sim >= self.config.compression_threshold]
             return kept[: self.config.top_k]
         except Exception as e:
             logger.warning("Post-compression failed: %s", e)

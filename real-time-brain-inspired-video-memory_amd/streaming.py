@@ -27,19 +27,28 @@ class StreamingSession:
         self.frames_in = torch.zeros((frames_per_chunk, height, width, 3), dtype=torch.uint8, device=dev)
         self.stream = torch.cuda.Stream(device=dev)
         self._appended_by_graph = 0
+        self._stager = None
         with torch.cuda.stream(self.stream):
-            for _ in range(warmup):  # allocate workspaces / set kernel attributes outside the capture
-                self._body()
+            # Warm up (code objects, kernel attributes, encoder workspace) against a scratch ring so that the user's
+            # memory is not touched: a graph capture records launches without running them.
+            scratch = EmbeddingMemory(max(4 * frames_per_chunk, 64), memory.dim, memory.dtype_name, ring=True,
+                                      device=dev.index or 0)
+            scratch.append(torch.zeros((1, memory.dim), dtype=memory.dtype, device=dev))
+            for _ in range(max(1, warmup)):
+                self._body(scratch)
+            scratch.close()
+            memory.prepare_topk(frames_per_chunk, top_k)
             self.stream.synchronize()
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, stream=self.stream):
-                self.emb, self.scores, self.rows = self._body()
+                self.emb, self.scores, self.rows = self._body(memory)
+            memory.sync()   # the capture advanced the host-side row count without appending anything: undo that
         self._host_rows = len(memory)
 
-    def _body(self) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    def _body(self, mem: EmbeddingMemory) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         emb = self.enc.embed_frames(self.frames_in)
-        scores, rows = self.mem.topk(emb, self.k, check_certified=False)   # uncertified queries are counted on device
-        self.mem.append(emb)
+        scores, rows = mem.topk(emb, self.k, check_certified=False)   # uncertified queries are counted on device
+        mem.append(emb)
         return emb, scores, rows
 
     def push(self, frames_u8: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
@@ -51,8 +60,41 @@ class StreamingSession:
         self._host_rows += self.frames_in.shape[0]
         return self.emb, self.scores, self.rows
 
+    # ---- host frames: pinned slots + copy stream, see ingest.FrameStager -------------------------
+    @property
+    def stager(self):
+        if self._stager is None:
+            from .ingest import FrameStager
+            F, H, W, _ = self.frames_in.shape
+            self._stager = FrameStager(F, H, W, device=self.enc.device.index or 0, depth=2)
+        return self._stager
+
+    def push_staged(self, ticket) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """Replay on a chunk whose H2D copy was started earlier (``stager.stage`` / ``next_slot`` + ``commit``); only
+        full chunks (the graph's shape).  The session stream waits for the copy, the host does not."""
+        if ticket.count != self.frames_in.shape[0]:
+            raise ValueError("the captured graph processes full chunks only")
+        with torch.cuda.stream(self.stream):
+            staged = self.stager.get(ticket)
+            self.frames_in.copy_(staged, non_blocking=True)   # D2D into the graph's input buffer (~80 us at 1080p)
+            self.stager.done(ticket)
+            self.graph.replay()
+        self._host_rows += self.frames_in.shape[0]
+        return self.emb, self.scores, self.rows
+
+    def push_host(self, frames) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """Host frames (uint8 BGR [F,H,W,3] array or list): stage + replay.  To overlap the next chunk's PCIe copy
+        with this replay, call ``stager.stage(next_frames)`` right after and ``push_staged`` it later."""
+        return self.push_staged(self.stager.stage(frames))
+
+    def sync(self) -> int:
+        """Wait for the replays issued so far and bring the memory's host-side tables in line (EmbeddingMemory.sync):
+        call before eager appends / exhaustive searches / snapshots on the same memory."""
+        with torch.cuda.stream(self.stream):
+            return self.mem.sync()
+
     @property
     def rows_appended(self) -> int:
-        """Host-side count of rows pushed through the graph (the library's own host mirror does not advance under
-        graph replay; the device-side counter does)."""
+        """Host-side count of rows in the memory including those pushed through the graph (the library's own host
+        mirror does not advance under graph replay; the device-side counter does, see ``sync``)."""
         return self._host_rows

@@ -89,11 +89,17 @@ def test_extractor_sources_and_json_shape(tmp_path):
             first = self.n; self.n += emb.shape[0]; return first
         def id_of(self, r): return None
 
+    class HostStager:  # ingest.FrameStager's interface without a device
+        def __init__(self, n, h, w, device): self.shape, self.staged = (n, h, w, 3), 0
+        def stage(self, fr): self.staged += 1; return torch.from_numpy(np.stack(fr))
+        def get(self, ticket): return ticket
+        def done(self, ticket): pass
+
     frames = np.zeros((35, 8, 8, 3), np.uint8)
     p = tmp_path / "clip.npz"
     np.savez(p, frames=frames, fps=np.float64(10.0))
     cfg = SimpleNamespace(video=SimpleNamespace(chunk_size_seconds=1.0, frames_per_chunk=16))
-    ex = X.FrameEmbeddingExtractor(cfg, FakeEnc(), FakeMem(), top_k=3)
+    ex = X.FrameEmbeddingExtractor(cfg, FakeEnc(), FakeMem(), top_k=3, stager_factory=HostStager)
     orig_sync = torch.cuda.synchronize
     torch.cuda.synchronize = lambda *a, **k: None
     try:
@@ -105,3 +111,4 @@ def test_extractor_sources_and_json_shape(tmp_path):
     assert [r["chunk_idx"] for r in d["results"]] == [0, 1, 2]
     assert set(d["results"][0]) >= {"time", "content", "chunk_idx", "processing_time"}  # vlm_extractor.py:66-71
     assert d["results"][2]["embedding_rows"] == list(range(20, 30)) and d["results"][1]["time"] == "00:01-00:02"
+    assert ex._stager.staged == 3 and ex._stager.shape == (16, 8, 8, 3)   # one staging per chunk, sized once

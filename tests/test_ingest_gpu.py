@@ -1,0 +1,120 @@
+"""GPU: frame ingest - pinned staging + copy stream must hand the kernels exactly the frames the
+host picked, with slots reused safely, and the pipelined extractor / streaming entry points must give the same
+embeddings and neighbours as the direct device-tensor path."""
+import asyncio
+import json
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_stager_slots_round_robin_and_ragged_chunks():
+    from vidmem.ingest import FrameStager
+    from vidmem import synthetic as syn
+    st = FrameStager(8, 90, 160, depth=2)
+    chunks = [syn.frames_u8(50 + i, n, 90, 160) for i, n in enumerate([8, 8, 3, 8, 1, 8])]
+    tickets, outs = [], []
+    for i, c in enumerate(chunks):                 # stage one ahead, consume one behind: slots get reused 3 times
+        tickets.append(st.stage(c if i % 2 else list(c)))
+        if i >= 1:
+            t = tickets[i - 1]
+            d = st.get(t)
+            outs.append(d.clone())                 # "kernel" reading the slot on the current stream
+            st.done(t)
+    d = st.get(tickets[-1]); outs.append(d.clone()); st.done(tickets[-1])
+    torch.cuda.synchronize()
+    for c, o in zip(chunks, outs):
+        assert o.shape[0] == c.shape[0] and np.array_equal(o.cpu().numpy(), c)
+    assert st.bytes_staged == sum(c.nbytes for c in chunks)
+    with pytest.raises(ValueError):
+        st.stage(np.zeros((9, 90, 160, 3), np.uint8))
+    with pytest.raises(ValueError):
+        st.stage([np.zeros((90, 161, 3), np.uint8)])
+    with pytest.raises(RuntimeError):
+        st.get(tickets[0])                          # long since restaged
+
+
+def test_next_slot_commit_in_place():
+    from vidmem.ingest import FrameStager
+    st = FrameStager(4, 32, 48, depth=2)
+    rng = np.random.default_rng(1)
+    want = []
+    for i in range(5):
+        view = st.next_slot()
+        view[:] = rng.integers(0, 256, view.shape, dtype=np.uint8)   # a decoder writing in place
+        want.append(view.copy())
+        t = st.commit(4)
+        got = st.get(t).clone(); st.done(t)
+        torch.cuda.synchronize()
+        assert np.array_equal(got.cpu().numpy(), want[-1])
+
+
+def test_extractor_pipeline_matches_direct_path(tmp_path):
+    """process_video on an .npz clip: embeddings appended to the memory and the neighbours written to the JSON equal
+    what the plain calls (device tensor in, no staging) give chunk by chunk."""
+    from vidmem import specs, synthetic as syn
+    from vidmem.encoder import FrameEncoder
+    from vidmem.memory import EmbeddingMemory
+    from vidmem.extractor import FrameEmbeddingExtractor, chunk_plan
+    spec = dict(specs.VIT_B16_224, layers=2)
+    enc = FrameEncoder(spec, syn.encoder_weights(spec, seed=8), "f16")
+    frames = syn.frames_u8(77, 50, 120, 200)
+    clip = tmp_path / "clip.npz"
+    np.savez(clip, frames=frames, fps=np.float64(10.0))
+    cfg = SimpleNamespace(video=SimpleNamespace(chunk_size_seconds=1.0, frames_per_chunk=6))
+    mem = EmbeddingMemory(256, 768, "f16")
+    ex = FrameEmbeddingExtractor(cfg, enc, mem, top_k=3)
+    out = json.load(open(asyncio.run(ex.process_video(str(clip), str(tmp_path / "out.json")))))
+    assert ex._stager.bytes_staged == 5 * 6 * 120 * 200 * 3
+
+    ref = EmbeddingMemory(256, 768, "f16")
+    _, plan = chunk_plan(10.0, 50, 1.0, 6)
+    assert [r["chunk_idx"] for r in out["results"]] == [p[0] for p in plan]
+    for res, (chunk_idx, start, end, idx, label) in zip(out["results"], plan):
+        emb = enc.embed_frames(torch.from_numpy(frames[idx]).cuda())
+        if ref.searchable:
+            s, r = ref.topk(emb, 3)
+            got = [[(rid, sc) for rid, sc in q] for q in res["similar"]]
+            want = [[(mem.id_of(ri), float(si)) for si, ri in zip(sq, rq) if ri >= 0]
+                    for sq, rq in zip(s.cpu().tolist(), r.cpu().tolist())]
+            assert [[tuple(x) for x in q] for q in got] == want
+        first = ref.append(emb)
+        assert res["embedding_rows"] == list(range(first, first + len(idx))) and res["time"] == label
+    assert torch.equal(ref.rows_tensor(), mem.rows_tensor())
+
+
+def test_streaming_push_host_equals_push_device():
+    from vidmem import specs, synthetic as syn
+    from vidmem.encoder import FrameEncoder
+    from vidmem.memory import EmbeddingMemory
+    from vidmem.streaming import StreamingSession
+    spec = dict(specs.VIT_B16_224, layers=1)
+    enc = FrameEncoder(spec, syn.encoder_weights(spec, seed=5), "f16")
+
+    def run(host):
+        mem = EmbeddingMemory(96, 768, "f16", ring=True)
+        mem.append(torch.from_numpy(syn.unit_rows(3, "seed", 40, 768)).to(torch.float16))
+        sess = StreamingSession(enc, mem, 8, 180, 320, top_k=4, warmup=1)
+        outs = []
+        nxt = sess.stager.stage(syn.frames_u8(200, 8, 180, 320)) if host else None
+        for step in range(5):
+            fr = syn.frames_u8(200 + step, 8, 180, 320)
+            if host:
+                cur = nxt
+                res = sess.push_staged(cur)
+                nxt = sess.stager.stage(syn.frames_u8(201 + step, 8, 180, 320))   # crosses PCIe under the replay
+            else:
+                res = sess.push(torch.from_numpy(fr).cuda())
+            torch.cuda.synchronize()
+            outs.append(tuple(t.clone() for t in res))
+        return outs, mem.rows_tensor().clone()
+
+    a, rows_a = run(False)
+    b, rows_b = run(True)
+    for (e1, s1, r1), (e2, s2, r2) in zip(a, b):
+        assert torch.equal(e1, e2) and torch.equal(s1, s2) and torch.equal(r1, r2)
+    assert torch.equal(rows_a, rows_b)
