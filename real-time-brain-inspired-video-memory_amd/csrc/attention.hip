@@ -118,6 +118,213 @@ __device__ __forceinline__ void attend_tile(const char *kl, const char *vl, type
     }
 }
 
+// Long rows (577 tokens: 37 key tiles): the whole score row does not fit in registers next to the accumulators
+// (148 VGPRs of scores alone; the single-pass tile spilled ~100 registers), so the row is walked twice - pass 1
+// computes the scores and keeps only the row maximum, pass 2 recomputes them 32 keys at a time, exponentiates against
+// the known maximum and feeds P.V.  Exactly the full-row softmax (no online rescaling), +50 % QK^T MFMAs (the matrix
+// pipe has the room), no spills.
+template <int DT, int NT, bool EXACT>
+__device__ __forceinline__ float attend_rowmax(const char *kl, typename vm_elem<DT>::vec8 qa,
+                                               typename vm_elem<DT>::vec8 qb, int T, int lane) {
+    using E = vm_elem<DT>;
+    using vec8 = typename E::vec8;
+    const int r16 = lane & 15, h = lane >> 4;
+    // (key & 7) == (r16 & 7) for every key tile: the two swizzled chunk addresses advance by 2 KiB per tile
+    const char *p0 = kl + r16 * 128 + ((h ^ (r16 & 7)) << 4);
+    const char *p1 = kl + r16 * 128 + (((h + 4) ^ (r16 & 7)) << 4);
+    auto tile = [&](int kt, bool masked) {
+        const vec8 k0 = *reinterpret_cast<const vec8 *>(p0 + kt * 2048);
+        const vec8 k1 = *reinterpret_cast<const vec8 *>(p1 + kt * 2048);
+        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+        a = E::mfma16(k0, qa, a);
+        a = E::mfma16(k1, qb, a);
+        if (masked) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] = (kt * 16 + 4 * h + j < T) ? a[j] : -INFINITY;
+        }
+        return fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
+    };
+    float mx0 = -INFINITY, mx1 = -INFINITY;
+    constexpr int FULL = EXACT ? NT - 1 : 0;   // tiles known to lie wholly below T
+    int kt = 0;
+#pragma unroll 1
+    for (; kt + 1 < FULL; kt += 2) {           // a real loop (two independent tiles per trip): unrolled, the
+        mx0 = fmaxf(mx0, tile(kt, false));     // scheduler hoists every K fragment read and spills ~240 registers
+        mx1 = fmaxf(mx1, tile(kt + 1, false));
+    }
+#pragma unroll 1
+    for (; kt < NT; ++kt) mx0 = fmaxf(mx0, tile(kt, kt >= FULL));
+    float mx = fmaxf(mx0, mx1);
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    return mx;
+}
+
+template <int DT, int NT, bool EXACT>
+__device__ __forceinline__ void attend_tile_pass2(const char *kl, const char *vl, typename vm_elem<DT>::vec8 qa,
+                                                  typename vm_elem<DT>::vec8 qb, float mx, int T, int lane,
+                                                  bool qvalid, uint16_t *dst_row) {
+    using E = vm_elem<DT>;
+    using vec8 = typename E::vec8;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef short s8v __attribute__((__vector_size__(8 * sizeof(short))));
+    constexpr int NS = (NT + 1) / 2;
+    const int r16 = lane & 15, h = lane >> 4;
+    const int tq = r16 >> 2, tp = r16 & 3;
+    const float scale_log2e = 0.125f * 1.44269504088896340736f;
+    const float neg_mxc = -mx * scale_log2e;
+    const f32x2 c2 = {scale_log2e, scale_log2e}, n2 = {neg_mxc, neg_mxc};
+    const char *p0 = kl + r16 * 128 + ((h ^ (r16 & 7)) << 4);
+    const char *p1 = kl + r16 * 128 + (((h + 4) ^ (r16 & 7)) << 4);
+    // V fragments: rows 32*ks + 4h + tq (+16); (row & 7) == ((4h + tq) & 7) for every step -> per-lane constants
+    const int vsw = (4 * h + tq) & 7;
+    const char *vrow = vl + (4 * h + tq) * 128 + (tp & 1) * 8;
+    int voff[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) voff[dt] = ((2 * dt + (tp >> 1)) ^ vsw) << 4;
+    f32x2 sum2 = {0.f, 0.f};
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto scores = [&](int kt, bool masked) {
+        const vec8 k0 = *reinterpret_cast<const vec8 *>(p0 + kt * 2048);
+        const vec8 k1 = *reinterpret_cast<const vec8 *>(p1 + kt * 2048);
+        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+        a = E::mfma16(k0, qa, a);
+        a = E::mfma16(k1, qb, a);
+        if (masked) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] = (kt * 16 + 4 * h + j < T) ? a[j] : -INFINITY;
+        }
+        return a;
+    };
+    auto step = [&](int ks, bool masked0, bool has1, bool masked1) {
+        f32x4 a[2];
+        a[0] = scores(2 * ks, masked0);
+        a[1] = has1 ? scores(2 * ks + 1, masked1) : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        uint16_t pe[8];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            f32x2 p01 = __builtin_elementwise_fma(f32x2{a[u][0], a[u][1]}, c2, n2);
+            f32x2 p23 = __builtin_elementwise_fma(f32x2{a[u][2], a[u][3]}, c2, n2);
+            p01 = f32x2{__builtin_amdgcn_exp2f(p01.x), __builtin_amdgcn_exp2f(p01.y)};
+            p23 = f32x2{__builtin_amdgcn_exp2f(p23.x), __builtin_amdgcn_exp2f(p23.y)};
+            sum2 += p01;
+            sum2 += p23;
+            pe[4 * u + 0] = E::from_float(p01.x);
+            pe[4 * u + 1] = E::from_float(p01.y);
+            pe[4 * u + 2] = E::from_float(p23.x);
+            pe[4 * u + 3] = E::from_float(p23.y);
+        }
+        vec8 pf;
+        __builtin_memcpy(&pf, pe, 16);
+        const char *row_lo = vrow + ks * 32 * 128;
+        const int hi_off = has1 ? 16 * 128 : 0;  // odd NT: the last half step re-reads valid rows against P = 0
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr)(row_lo + voff[dt]));
+            const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr)(row_lo + hi_off + voff[dt]));
+            const s8v av = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            o[dt] = E::mfma16(__builtin_bit_cast(vec8, av), pf, o[dt]);
+        }
+    };
+    constexpr int FULL_STEPS = EXACT ? (NT - 1) / 2 : 0;  // 32-key steps whose two tiles lie wholly below T
+    int ks = 0;
+#pragma unroll 1
+    for (; ks < FULL_STEPS; ++ks) step(ks, false, true, false);
+#pragma unroll 1
+    for (; ks < NS; ++ks) step(ks, true, 2 * ks + 1 < NT, true);
+
+    float sum = sum2.x + sum2.y;
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    if (qvalid) {
+        uint16_t *dst = dst_row + 4 * h;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            uint16_t oe[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) oe[j] = E::from_float(o[dt][j] * inv);
+            uint2 pk;
+            __builtin_memcpy(&pk, oe, 8);
+            *reinterpret_cast<uint2 *>(dst + dt * 16) = pk;
+        }
+    }
+}
+
+// One workgroup of NW waves per (frame, head): K rows by LDS-DMA, barrier; the V rows' LDS-DMA is issued next and
+// lands while every wave runs pass 1 of its first query tile; then tiles wave, wave + NW, ...
+template <int DT, int NT, bool EXACT, int NW>
+__global__ void __launch_bounds__(NW * 64, 1)
+    attention_long_kernel(const uint16_t *__restrict__ qkv, uint16_t *__restrict__ ctx_out, int T, int heads) {
+    using E = vm_elem<DT>;
+    using vec8 = typename E::vec8;
+    constexpr int ROWS = NT * 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *kl = smem, *vl = smem + (size_t)ROWS * 128;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, h = lane >> 4;
+    const int b = blockIdx.x / heads, head = blockIdx.x - b * heads;
+    const int H = heads * 64;
+    const size_t M = (size_t)(gridDim.x / heads) * T;
+    auto block = [&](int part) { return qkv + ((size_t)(part * heads + head) * M + (size_t)b * T) * 64; };
+    auto load_q = [&](int qt, vec8 &q0, vec8 &q1) {
+        int qtok = qt * 16 + r16;
+        if (qtok > T - 1) qtok = T - 1;
+        const uint16_t *qp = block(0) + (size_t)qtok * 64;
+        q0 = __builtin_bit_cast(vec8, *reinterpret_cast<const uint4 *>(qp + 8 * h));
+        q1 = __builtin_bit_cast(vec8, *reinterpret_cast<const uint4 *>(qp + 32 + 8 * h));
+    };
+    const int srow = lane >> 3, scp = lane & 7;
+    auto stage = [&](int part, char *dst) {  // rows past T re-read row T-1 (masked / P = 0 later)
+        const char *src = reinterpret_cast<const char *>(block(part));
+#pragma unroll 4
+        for (int grp = wave; grp < ROWS / 8; grp += NW) {
+            int key = grp * 8 + srow;
+            key = key > T - 1 ? T - 1 : key;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + (size_t)key * 128 + ((scp ^ srow) << 4)),
+                                             (lds_ptr_t)(dst + grp * 1024), 16, 0, 0);
+        }
+    };
+    vec8 q0, q1;
+    load_q(wave, q0, q1);
+    stage(1, kl);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    stage(2, vl);
+    float mx = attend_rowmax<DT, NT, EXACT>(kl, q0, q1, T, lane);  // needs K only: overlaps the V fill
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int qt = wave; qt < NT; qt += NW) {
+        const int qtok = qt * 16 + r16;
+        const bool qvalid = qtok < T;
+        const vec8 qa = q0, qb = q1;
+        if (qt + NW < NT) load_q(qt + NW, q0, q1);
+        if (qt != wave) mx = attend_rowmax<DT, NT, EXACT>(kl, qa, qb, T, lane);
+        attend_tile_pass2<DT, NT, EXACT>(kl, vl, qa, qb, mx, T, lane, qvalid,
+                                         ctx_out + ((size_t)b * T + (qvalid ? qtok : 0)) * H + head * 64);
+    }
+}
+
+template <int DT, int NT, bool EXACT>
+int launch_long(vm_ctx *ctx, const uint16_t *qkv, uint16_t *out, int B, int T, int heads, hipStream_t st) {
+    const size_t lds = (size_t)NT * 16 * 128 * 2;
+    // 16 waves (4 per SIMD; the kernel needs ~80 VGPRs): 21.1 ms vs 27.0 ms with 8 waves per 256-frame CLIP-L pass
+    auto kern = attention_long_kernel<DT, NT, EXACT, 16>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        VM_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    vm_prof_scope prof(ctx, VM_PROF_ATTENTION, st);
+    kern<<<B * heads, 1024, lds, st>>>(qkv, out, T, heads);
+    VM_LAUNCH_CHECK(ctx);
+    return VM_OK;
+}
+
 // NT = key tiles of 16 (13 for 197 tokens, 37 for 577).  EXACT: T > 16*(NT-1), so only the last tile has masked keys
 // and the mask is resolved at compile time for every other tile.
 template <int DT, int NT, bool EXACT, int OCC>
@@ -297,11 +504,11 @@ int dispatch(vm_ctx *ctx, const uint16_t *qkv, uint16_t *out, int B, int T, int 
     if (nt == 13) {  // ViT-B/16-224: 197 tokens
         return launch_stream<DT, 13, true>(ctx, qkv, out, B, T, heads, st);
     }
-    if (nt == 37) return launch<DT, 37, true>(ctx, qkv, out, B, T, heads, st);   // CLIP-L/14-336: 577 tokens
+    if (nt == 37) return launch_long<DT, 37, true>(ctx, qkv, out, B, T, heads, st);   // CLIP-L/14-336: 577 tokens
     if (nt <= 2) return launch<DT, 2, false>(ctx, qkv, out, B, T, heads, st);
     if (nt <= 5) return launch<DT, 5, false>(ctx, qkv, out, B, T, heads, st);
     if (nt <= 13) return launch<DT, 13, false>(ctx, qkv, out, B, T, heads, st);
-    if (nt <= 37) return launch<DT, 37, false>(ctx, qkv, out, B, T, heads, st);
+    if (nt <= 37) return launch_long<DT, 37, false>(ctx, qkv, out, B, T, heads, st);
     return vm_fail(ctx, VM_ERR_UNSUPPORTED, "attention: %d tokens > 592", T);
 }
 
