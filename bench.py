@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--no-knn", action="store_true")
     ap.add_argument("--knn-rows", type=int, default=1_000_000)
     ap.add_argument("--no-streaming", action="store_true")
+    ap.add_argument("--no-c3", action="store_true", help="skip the CLIP-ViT-L/14-336 bf16 leg (BASELINE configs[2])")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI); gloo only to rehearse N>1 on one GPU")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--stream-rows", type=int, default=2_097_152, help="rolling memory rows of the C5 latency leg")
@@ -324,6 +325,50 @@ def main():
         }
         del sess, chunk
         ring.close()
+
+    # ---- BASELINE configs[2] leg: CLIP-ViT-L/14-336 bf16 encoder + top-20 over a 1M x 1024 bf16 index --------------
+    if rank == 0 and not args.no_c3:
+        del enc
+        torch.cuda.empty_cache()
+        spec3 = specs.CLIP_L14_336
+        enc3 = FrameEncoder(spec3, syn.encoder_weights(spec3, seed=42), dtype="bf16", device=local_rank)
+        g3 = torch.Generator(device=dev).manual_seed(4321)
+        F3 = 226                                      # two micro-batches of 113 frames (4 GEMM tile rounds each)
+        fr3 = torch.randint(0, 256, (F3, 336, 336, 3), generator=g3, device=dev, dtype=torch.uint8)
+        M3, D3, k3 = 1_000_000, 1024, 20
+        mem3 = EmbeddingMemory(M3, D3, "bf16", device=local_rank)
+        for lo in range(0, M3, 250_000):
+            x = torch.randn((250_000, D3), generator=g3, device=dev, dtype=torch.float32)
+            mem3.append((x / x.norm(dim=1, keepdim=True)).to(torch.bfloat16))
+        for _ in range(2):
+            e3 = enc3.embed_frames(fr3)
+            mem3.topk(e3[:16], k3, check_certified=False)
+        torch.cuda.synchronize()
+        reps = 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            e3 = enc3.embed_frames(fr3)
+        torch.cuda.synchronize()
+        dt_enc = (time.perf_counter() - t0) / reps
+        t0 = time.perf_counter()
+        for _ in range(20):
+            mem3.topk(e3[:16], k3, check_certified=False)
+        torch.cuda.synchronize()
+        dt_knn = (time.perf_counter() - t0) / 20
+        ctx.profile_enable(4096)
+        enc3.embed_frames(fr3)
+        bd3 = ctx.profile_read()
+        ctx.profile_enable(0)
+        out["c3"] = {
+            "workload": f"BASELINE configs[2]: CLIP-ViT-L/14-336 bf16, {F3} frames per pass; top-{k3} of 16 queries "
+                        f"over {M3} x {D3} bf16",
+            "frames_per_s": F3 / dt_enc, "encoder_tflops": F3 / dt_enc * specs.flops_per_frame(spec3) / 1e12,
+            "knn_queries_per_s": 16 / dt_knn, "knn_scan_GBps": M3 * D3 * 2 / dt_knn / 1e9,
+            "uncertified_queries": int(mem3._uncert.item()),
+            "kernel_time_ms_per_pass": {c: round(v[0], 3) for c, v in bd3.items() if v[1]},
+        }
+        mem3.close()
+        del enc3, fr3
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         fr = syn.frames_u8(1234, 4, 224, 224)
