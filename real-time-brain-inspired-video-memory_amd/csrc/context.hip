@@ -115,9 +115,17 @@ __device__ __forceinline__ void axis_tap(int d, float scale, int n, int &i0, int
     lam = src - (float)f;
 }
 
-template <int DT>
-__global__ void __launch_bounds__(256) preprocess_kernel(PreArgs p) {
+// PATCH / KPAD: compile-time patch edge and padded row length for the two encoder families (16 / 768, 14 / 640), 0 = read
+// them from the arguments.  With constants every index division below becomes a multiply-shift; with run-time
+// divisors the kernel was integer-division bound (0.58 ms for 880 frames, ~9x its HBM time).
+template <int DT, int PATCH, int KPAD>
+__global__ void __launch_bounds__(256) preprocess_kernel(PreArgs p0) {
     using E = vm_elem<DT>;
+    PreArgs p = p0;
+    if (PATCH) {
+        p.patch = PATCH;
+        p.k_pad = KPAD;
+    }
     const int g = p.patch > 0 ? p.S / p.patch : 0;
     const int pp = p.patch * p.patch;
     const int64_t per_frame =
@@ -125,8 +133,16 @@ __global__ void __launch_bounds__(256) preprocess_kernel(PreArgs p) {
     const int64_t total = per_frame * p.B;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
-        const int b = (int)(idx / per_frame);
-        const int64_t r = idx - (int64_t)b * per_frame;
+        int b;
+        int64_t r;
+        if (total < ((int64_t)1 << 31)) {  // the usual case: 32-bit division (the 64-bit one costs ~100 instructions)
+            const unsigned i32 = (unsigned)idx, pf32 = (unsigned)per_frame;
+            b = (int)(i32 / pf32);
+            r = (int64_t)(i32 - (unsigned)b * pf32);
+        } else {
+            b = (int)(idx / per_frame);
+            r = idx - (int64_t)b * per_frame;
+        }
         const uint8_t *frame = p.src + (size_t)b * p.H * p.W * 3;
         uint16_t o8[8];
 #pragma unroll
@@ -218,10 +234,19 @@ extern "C" int vm_preprocess(vm_ctx *ctx, const uint8_t *frames, int B, int H, i
     if (blocks > cap) blocks = cap;
     hipStream_t st = (hipStream_t)stream;
     vm_prof_scope prof(ctx, VM_PROF_PREPROCESS, st);
+    const bool p16 = layout == VM_LAYOUT_PATCHES && patch == 16 && k_pad == 768;
+    const bool p14 = layout == VM_LAYOUT_PATCHES && patch == 14 && k_pad == 640;
+#define VM_PRE(DT)                                                                      \
+    do {                                                                                \
+        if (p16) preprocess_kernel<DT, 16, 768><<<(unsigned)blocks, 256, 0, st>>>(p);   \
+        else if (p14) preprocess_kernel<DT, 14, 640><<<(unsigned)blocks, 256, 0, st>>>(p); \
+        else preprocess_kernel<DT, 0, 0><<<(unsigned)blocks, 256, 0, st>>>(p);          \
+    } while (0)
     if (dtype == VM_F16)
-        preprocess_kernel<VM_F16><<<(unsigned)blocks, 256, 0, st>>>(p);
+        VM_PRE(VM_F16);
     else
-        preprocess_kernel<VM_BF16><<<(unsigned)blocks, 256, 0, st>>>(p);
+        VM_PRE(VM_BF16);
+#undef VM_PRE
     VM_LAUNCH_CHECK(ctx);
     return VM_OK;
 }
