@@ -150,3 +150,30 @@ def test_batching_is_invisible(monkeypatch):
     tail = enc.embed_frames(frames[147:])
     assert torch.equal(all_emb[:3], head) and torch.equal(all_emb[147:], tail)
     assert torch.isfinite(all_emb.float()).all()
+
+
+@pytest.mark.parametrize("name,dtype,n", [("vit_b16_224", "f16", 500), ("clip_l14_336", "bf16", 120)])
+def test_bench_size_batches_take_the_big_kernels_and_agree(name, dtype, n):
+    """BASELINE-size micro-batches (441 ViT-B frames / 113 CLIP-L frames per pass) run the persistent 256x256 GEMM
+    (ragged last row panel, head-major QKV stores) and the streaming / two-pass attention kernels, which the few-frame
+    tests above never reach.  Size-independent checks: (1) every frame's embedding equals what the same frame gets
+    in a 3-frame launch (128x128 GEMM, one attention item per workgroup) BIT FOR BIT - both tilings accumulate each
+    output in the same MFMA order, so any difference is a misplaced tile or a stale LDS image; (2) a sample of frames against the quant-aware oracle at the parity bar."""
+    from vidmem import synthetic as syn
+    spec = V.SPECS[name]
+    w = syn.encoder_weights(spec, seed=21)
+    enc = _encoder(spec, w, dtype)
+    S = spec["image"]
+    frames = torch.from_numpy(syn.frames_u8(500, n, S, S)).cuda()
+    big = enc.embed_frames(frames)
+    assert torch.isfinite(big.float()).all()
+    picks = [0, 1, 2, n // 2, n // 2 + 1, n // 2 + 2, n - 3, n - 2, n - 1]   # first / middle / ragged-tail panels
+    worst = 0.0
+    for lo in (0, n // 2, n - 3):
+        small = enc.embed_frames(frames[lo:lo + 3])
+        worst = max(worst, rel(big[lo:lo + 3].float().cpu().numpy(), small.float().cpu().numpy()))
+    print(f"{name}: big-batch vs 3-frame launches, worst rel diff {worst:.2e}")
+    assert worst == 0.0
+    px = F.preprocess_ref(frames[picks[:3]].cpu().numpy(), S, spec["mean"], spec["std"], layout="chw")
+    want = V.vit_forward_ref(spec, w, px, quant=dtype)
+    assert rel(big[:3].float().cpu().numpy(), want) < REL_TOL[dtype]
