@@ -184,7 +184,7 @@ def test_full_size_properties_1m_rows():
 
 
 def test_sampled_cut_path_many_queries_bit_exact():
-    """Q >= 32 on a memory >= 131072 rows takes the sampling pre-pass (csrc/topk.hip SAMPLE_ROWS): the cut must not
+    """Q >= 32 on a memory >= 65536 rows takes the sampling pre-pass (csrc/topk.hip SAMPLE_ROWS): the cut must not
     change a single row or score bit, including duplicates that straddle the sample boundary."""
     rng = np.random.default_rng(21)
     D, M, Q, k = 256, 140_000, 40, 10
