@@ -183,16 +183,17 @@ def test_full_size_properties_1m_rows():
     assert np.array_equal(r2.cpu().numpy(), r_np[5:6]) and np.array_equal(s2.cpu().numpy(), s_np[5:6])
 
 
-def test_sampled_cut_path_many_queries_bit_exact():
+@pytest.mark.parametrize("M", [70_000, 140_000])
+def test_sampled_cut_path_many_queries_bit_exact(M):
     """Q >= 32 on a memory >= 65536 rows takes the sampling pre-pass (csrc/topk.hip SAMPLE_ROWS): the cut must not
     change a single row or score bit, including duplicates that straddle the sample boundary."""
     rng = np.random.default_rng(21)
-    D, M, Q, k = 256, 140_000, 40, 10
+    D, Q, k = 256, 40, 10
     m = torch.tensor(rng.standard_normal((M, D)), dtype=torch.float32).to(torch.float16)
     q = torch.tensor(rng.standard_normal((Q, D)), dtype=torch.float32).to(torch.float16)
-    q[:8] = (0.7 * m[[3, 16_383, 16_384, 70_000, 139_999, 5, 6, 7]].float() + 0.3 * q[:8].float()).to(torch.float16)
+    q[:8] = (0.7 * m[[3, 16_383, 16_384, M // 2, M - 1, 5, 6, 7]].float() + 0.3 * q[:8].float()).to(torch.float16)
     m[20_000] = m[3]        # duplicate outside the sample of a row inside it
-    m[100] = m[139_999]     # and the other way round
+    m[100] = m[M - 1]       # and the other way round
     q[9] = 0                # zero query: all scores 0.0, first k rows win
     mem = _mem("f16", M, D)
     mem.append(m)
