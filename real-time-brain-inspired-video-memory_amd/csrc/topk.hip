@@ -222,24 +222,68 @@ __global__ void __launch_bounds__(SCAN_THREADS)
             }
     }
     __syncthreads();
-    // cross-wave merge by rank counting: nw*KL candidates per query, strict order (score, order, candidate idx)
-    const int ncand = nw * KL;
-    for (int pq = wave; pq < QT * 16; pq += nw) {  // pq = t*16 + r
-        for (int c = lane; c < ncand; c += 64) {
-            const int cw = c / KL, ci = c - cw * KL;
-            const float s = ms[((cw * QT * 16) + pq) * KL + ci];
-            const int o = mo[((cw * QT * 16) + pq) * KL + ci];
-            int rank = 0;
-            for (int d = 0; d < ncand; ++d) {
-                const int dw = d / KL, di = d - dw * KL;
-                const float s2 = ms[((dw * QT * 16) + pq) * KL + di];
-                const int o2 = mo[((dw * QT * 16) + pq) * KL + di];
-                rank += (better(s2, o2, s, o) || (s2 == s && o2 == o && d < c)) ? 1 : 0;
+    // cross-wave merge with the same network: query tile t goes to wave t; its lane (r16, h) picks up the lists of
+    // waves h, h + 4, ... for query (t, r16), merges them in registers, and the four lane groups merge as above.
+    // (The first version ranked all nw*KL candidates against each other out of LDS: ~10 k VALU instructions per wave,
+    // as much as scanning 30 row tiles, and the reason more row-blocks made multi-tile scans slower.)
+    static_assert(SCAN_THREADS % 256 == 0, "the cross-wave merge maps waves 4g + h onto lane group h");
+    for (int t = wave; t < QT; t += nw) {
+        float fs[KL];
+        int fo[KL];
+#pragma unroll
+        for (int i = 0; i < KL; ++i) {
+            fs[i] = ms[((h * QT + t) * 16 + r16) * KL + i];
+            fo[i] = mo[((h * QT + t) * 16 + r16) * KL + i];
+        }
+#pragma unroll 1  // ONE copy of the network in the code: unrolled, this block took the compiler > 30 minutes
+        for (int round = 1; round < nw / 4 + 2; ++round) {
+            // rounds 1 .. nw/4-1: list of wave h + 4*round from LDS; last two rounds: lane partners ^16, ^32
+            float ps[KL];
+            int po[KL];
+            if (round < nw / 4) {
+#pragma unroll
+                for (int i = 0; i < KL; ++i) {
+                    ps[i] = ms[(((h + 4 * round) * QT + t) * 16 + r16) * KL + (KL - 1 - i)];
+                    po[i] = mo[(((h + 4 * round) * QT + t) * 16 + r16) * KL + (KL - 1 - i)];
+                }
+            } else {
+                const int step = round == nw / 4 ? 16 : 32;
+#pragma unroll
+                for (int i = 0; i < KL; ++i) {
+                    ps[i] = __shfl_xor(fs[KL - 1 - i], step, 64);
+                    po[i] = __shfl_xor(fo[KL - 1 - i], step, 64);
+                }
             }
-            if (rank < KL) {
-                const size_t dst = ((size_t)blockIdx.x * q_pad + q0 + pq) * KL + rank;
-                part_s[dst] = s;
-                part_o[dst] = o;
+#pragma unroll
+            for (int i = 0; i < KL; ++i) {
+                const bool take = better(ps[i], po[i], fs[i], fo[i]);
+                fs[i] = take ? ps[i] : fs[i];
+                fo[i] = take ? po[i] : fo[i];
+            }
+#pragma unroll
+            for (int stride = KL / 2; stride > 0; stride >>= 1) {
+#pragma unroll
+                for (int i = 0; i < KL; ++i) {
+                    if ((i & stride) == 0) {
+                        const bool sw = better(fs[i + stride], fo[i + stride], fs[i], fo[i]);
+                        const float s_hi = sw ? fs[i + stride] : fs[i];
+                        const float s_lo = sw ? fs[i] : fs[i + stride];
+                        const int o_hi = sw ? fo[i + stride] : fo[i];
+                        const int o_lo = sw ? fo[i] : fo[i + stride];
+                        fs[i] = s_hi;
+                        fs[i + stride] = s_lo;
+                        fo[i] = o_hi;
+                        fo[i + stride] = o_lo;
+                    }
+                }
+            }
+        }
+        if (h == 0) {
+            const size_t dst = ((size_t)blockIdx.x * q_pad + q0 + t * 16 + r16) * KL;
+#pragma unroll
+            for (int i = 0; i < KL; ++i) {
+                part_s[dst + i] = fs[i];
+                part_o[dst + i] = fo[i];
             }
         }
     }
