@@ -245,7 +245,7 @@ def main():
             big.append((x / x.norm(dim=1, keepdim=True)).to(torch.float16))
         out["knn"] = {"index": f"{Mk} x {D} f16", "k": k, "batches": {}}
         bytes_scan = Mk * D * 2
-        for Qk in (16, 64):
+        for Qk in (16, 64, 256):
             q = torch.randn((Qk, D), generator=gk, device=dev, dtype=torch.float32).to(torch.float16)
             for _ in range(3):
                 big.topk(q, k, check_certified=False)

@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(SCAN_THREADS)
     topk_scan_kernel(const uint16_t *__restrict__ mem, const float *__restrict__ rnorm,
                      const uint16_t *__restrict__ queries, const int64_t *__restrict__ d_total, int64_t cap,
                      int ring, int D, int Q, int q_pad, float *__restrict__ part_s, int *__restrict__ part_o,
-                     int64_t row_limit, const float *__restrict__ thr_s, const int *__restrict__ thr_o) {
+                     int64_t row_limit, const float *__restrict__ thr_s, const int *__restrict__ thr_o, int qgroups) {
     using E = vm_elem<DT>;
     using vec8 = typename E::vec8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -90,7 +90,19 @@ __global__ void __launch_bounds__(SCAN_THREADS)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, h = lane >> 4;
-    const int q0 = blockIdx.y * (QT * 16);
+    // Workgroup -> (row block bx of nbx, query group by).  With several query groups the launch is 1-D and remapped
+    // so that the groups of one row block are neighbours ON ONE XCD (workgroup id % 8 picks the XCD): they stream the
+    // same rows at the same pace, so one of them pulls a row from HBM / MALL and the others hit that XCD's L2.
+    int bx = blockIdx.x, by = blockIdx.y, nbx = gridDim.x;
+    if (qgroups > 1) {
+        const int total = gridDim.x, id = blockIdx.x;
+        int v = id;
+        if ((total & 7) == 0) v = (id & 7) * (total >> 3) + (id >> 3);
+        nbx = total / qgroups;
+        bx = v / qgroups;
+        by = v - bx * qgroups;
+    }
+    const int q0 = by * (QT * 16);
 
     // stage the query tile: chunk ci of query q sits at (ci & ~15) | ((ci ^ q) & 15)
     for (int idx = tid; idx < QT * 16 * chunks; idx += SCAN_THREADS) {
@@ -126,30 +138,56 @@ __global__ void __launch_bounds__(SCAN_THREADS)
         to[t] = have ? thr_o[q0 + 16 * t + r16] : INT_MAX;
     }
 
-    for (int64_t tile = (int64_t)blockIdx.x * nw + wave; tile < ntiles; tile += (int64_t)gridDim.x * nw) {
+    // Row data goes global -> registers in batches of LB 16-byte loads per lane (8 KiB per wave).  The NEXT batch -
+    // of this row tile or of the wave's next one - is issued before the MFMAs of the current batch: with two waves per
+    // SIMD (the per-lane lists fill the register file) nothing else hides the HBM latency, and without the prefetch
+    // a multi-tile scan spent ~9 us per row tile waiting for three round trips.
+    constexpr int LB = 8;
+    const int64_t tile_step = (int64_t)nbx * nw;
+    auto src_of = [&](int64_t tile) {
         int64_t row = tile * 16 + r16;
         if (row > rv.n - 1) row = rv.n - 1;  // tail lanes re-read the last row; their scores are masked below
-        const uint4 *src = reinterpret_cast<const uint4 *>(mem + (size_t)row * D) + h;
+        return reinterpret_cast<const uint4 *>(mem + (size_t)row * D) + h;
+    };
+    auto issue = [&](const uint4 *src, int s0, uint4 (&a)[LB]) {
+#pragma unroll
+        for (int u = 0; u < LB; ++u) a[u] = src[(s0 + u < ksteps ? s0 + u : ksteps - 1) * 4];
+    };
+    // (single-tile scans, QT == 1, run three waves per SIMD and are HBM-bound at 5.5 TB/s without it; there the extra
+    // registers and copies cost 15 %, so they keep the plain load-then-use order)
+    constexpr bool PREFETCH = QT >= 2;
+    uint4 cur[LB];
+    const int64_t tile0 = (int64_t)bx * nw + wave;
+    if (PREFETCH && tile0 < ntiles) issue(src_of(tile0), 0, cur);
+    for (int64_t tile = tile0; tile < ntiles; tile += tile_step) {
+        const uint4 *src = src_of(tile);
         f32x4 acc[QT];
 #pragma unroll
         for (int t = 0; t < QT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // LB independent 16-byte loads per lane are issued before their first use (8 KiB in flight per wave)
-        constexpr int LB = 8;
         for (int s0 = 0; s0 < ksteps; s0 += LB) {
-            uint4 a[LB];
-#pragma unroll
-            for (int u = 0; u < LB; ++u) a[u] = src[(s0 + u < ksteps ? s0 + u : ksteps - 1) * 4];
+            uint4 nxt[LB];
+            if (!PREFETCH) {
+                issue(src, s0, cur);
+            } else if (s0 + LB < ksteps) {
+                issue(src, s0 + LB, nxt);
+            } else if (tile + tile_step < ntiles) {
+                issue(src_of(tile + tile_step), 0, nxt);
+            }
 #pragma unroll
             for (int u = 0; u < LB; ++u) {
                 if (s0 + u < ksteps) {  // ksteps is a multiple of 4; uniform branch
                     const int ci = h + 4 * (s0 + u);
-                    const vec8 av = __builtin_bit_cast(vec8, a[u]);
+                    const vec8 av = __builtin_bit_cast(vec8, cur[u]);
 #pragma unroll
                     for (int t = 0; t < QT; ++t) {
                         const uint4 bq = qlds[(t * 16 + r16) * chunks + ((ci & ~15) | ((ci ^ r16) & 15))];
                         acc[t] = E::mfma16(av, __builtin_bit_cast(vec8, bq), acc[t]);
                     }
                 }
+            }
+            if (PREFETCH) {
+#pragma unroll
+                for (int u = 0; u < LB; ++u) cur[u] = nxt[u];
             }
         }
         // acc[t][j] = <row tile*16 + 4h + j , query q0 + 16t + r16>
@@ -279,7 +317,7 @@ __global__ void __launch_bounds__(SCAN_THREADS)
             }
         }
         if (h == 0) {
-            const size_t dst = ((size_t)blockIdx.x * q_pad + q0 + t * 16 + r16) * KL;
+            const size_t dst = ((size_t)bx * q_pad + q0 + t * 16 + r16) * KL;
 #pragma unroll
             for (int i = 0; i < KL; ++i) {
                 part_s[dst + i] = fs[i];
@@ -652,10 +690,10 @@ int launch_scan(vm_memory *m, const ScanPlan &p, int nblk, int64_t row_limit, co
                                            (int)p.lds);
         if (e != hipSuccess) return vm_fail(m->ctx, VM_ERR_HIP, "LDS opt-in %zu: %s", p.lds, hipGetErrorString(e));
     }
-    dim3 grid(nblk, p.qgroups);
+    const dim3 grid = p.qgroups > 1 ? dim3(nblk * p.qgroups) : dim3(nblk);
     vm_prof_scope prof(m->ctx, VM_PROF_TOPK_SCAN, st);
     kern<<<grid, SCAN_THREADS, p.lds, st>>>(m->rows, m->rnorm32, (const uint16_t *)queries, m->d_total, m->cap,
-                                          m->ring, m->D, Q, p.q_pad, part_s, part_o, row_limit, thr_s, thr_o);
+                                          m->ring, m->D, Q, p.q_pad, part_s, part_o, row_limit, thr_s, thr_o, p.qgroups);
     VM_LAUNCH_CHECK(m->ctx);
     return VM_OK;
 }

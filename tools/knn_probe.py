@@ -8,7 +8,7 @@ mem = EmbeddingMemory(M, D, "f16")
 g = torch.Generator(device="cuda").manual_seed(7)
 for lo in range(0, M, 250_000):
     x = torch.randn((250_000, D), generator=g, device="cuda"); mem.append((x / x.norm(dim=1, keepdim=True)).half())
-for Q in (1, 16, 64):
+for Q in (16, 64, 256):
     q = torch.randn((Q, D), generator=g, device="cuda").half()
     for _ in range(3): mem.topk(q, 10, check_certified=False)
     torch.cuda.synchronize(); mem.ctx.profile_enable(512)
