@@ -339,7 +339,7 @@ __global__ void __launch_bounds__(FIN_THREADS)
                          const int *__restrict__ part_o, int k, int use_min, double min_score, int score_mode,
                          int64_t row_stride, int64_t row_offset, double *__restrict__ out_scores,
                          int64_t *__restrict__ out_rows, int *__restrict__ uncertified,
-                         float *__restrict__ thr_s_out, int *__restrict__ thr_o_out) {
+                         float *__restrict__ thr_s_out, int *__restrict__ thr_o_out, int stage_rows) {
     using E = vm_elem<DT>;
     __shared__ float hs[MAX_BLOCKS];
     __shared__ int ho[MAX_BLOCKS];
@@ -352,6 +352,8 @@ __global__ void __launch_bounds__(FIN_THREADS)
     __shared__ double qnorm_sh;
     __shared__ float qsq_sh[FIN_THREADS / 64];
     __shared__ int cnt, nqual;
+    __shared__ float cut_s_sh;
+    __shared__ int cut_o_sh;
     extern __shared__ __attribute__((aligned(16))) char fin_dyn[];  // the query row, [D] 16-bit
     uint16_t *ql = reinterpret_cast<uint16_t *>(fin_dyn);
 
@@ -442,14 +444,25 @@ __global__ void __launch_bounds__(FIN_THREADS)
             const bool take = want > 0 && key[i] != 0u && (key[i] > tk || (key[i] == tk && ord[i] <= to));
             if (take) qual[atomicAdd(&nqual, 1)] = tid + 64 * i;
         }
+        if (tid == 0) {
+            // The KL-th best HEAD is a lower bound of the KL-th best candidate overall (KL distinct candidates are at
+            // least that good), so members of the qualified lists strictly below it cannot reach the top KL: they
+            // are dropped before the O(C^2) rank count (C <= KL^2 without the cut: 0.4 ms per launch at KL = 32).
+            const bool have_cut = want == KL;
+            const unsigned u = (tk & 0x80000000u) ? (tk & 0x7fffffffu) : ~tk;
+            cut_s_sh = have_cut ? __builtin_bit_cast(float, u) : -INFINITY;
+            cut_o_sh = have_cut ? to : INT_MAX;
+        }
     }
     __syncthreads();
     const int nq_lists = nqual;
+    const float cut_s = cut_s_sh;
+    const int cut_o = cut_o_sh;
     for (int p = tid; p < nq_lists * KL; p += FIN_THREADS) {
         const int b = qual[p / KL], e = p % KL;
         const float s = part_s[((size_t)b * q_pad + q) * KL + e];
         const int o = part_o[((size_t)b * q_pad + q) * KL + e];
-        if (s > -INFINITY) {
+        if (s > -INFINITY && !better(cut_s, cut_o, s, o)) {
             const int slot = atomicAdd(&cnt, 1);
             cs[slot] = s;
             co[slot] = o;
@@ -485,6 +498,24 @@ __global__ void __launch_bounds__(FIN_THREADS)
     //  * otherwise (bf16, or large norms): one thread sums strictly left to right, as the reference does.
     // The query norm is handled the same way by the last wave's first TPC threads' neighbours (slot KL).
     const uint16_t *qv = ql;  // LDS copy of the query row
+    // bf16 has no order-free fast path (its products span too many binades), so every candidate is summed strictly
+    // left to right by one thread.  Fed from global memory that chain waits one load round trip per 32 elements
+    // (0.43 ms per launch at k = 20, D = 1024); the candidates' rows are therefore staged in LDS first, by all
+    // threads, coalesced.  Row pitch D + 8 elements: the one-thread-per-row readers land on different banks.
+    const bool STAGED = DT == VM_BF16 && stage_rows;  // block-uniform
+    const int RS = D + 8;
+    uint16_t *rows_l = ql + D;
+    if (STAGED) {
+        const int cpr = D / 8;
+        for (int idx = tid; idx < nfin * cpr; idx += FIN_THREADS) {
+            const int c = idx / cpr, ch = idx - c * cpr;
+            int64_t p = fo[c] + rv.head;
+            if (p >= rv.cap) p -= rv.cap;
+            *reinterpret_cast<uint4 *>(rows_l + (size_t)c * RS + ch * 8) =
+                *reinterpret_cast<const uint4 *>(mem + (size_t)p * D + ch * 8);
+        }
+        __syncthreads();
+    }
     const double qnorm_fast = 1.001 * sqrt((double)((qsq_sh[0] + qsq_sh[1]) + (qsq_sh[2] + qsq_sh[3])));
     constexpr int TPC = FIN_THREADS / KL;  // 4 .. 32, a power of two dividing the wave
     {
@@ -492,7 +523,7 @@ __global__ void __launch_bounds__(FIN_THREADS)
         const bool live = c < nfin;
         int64_t p = live ? fo[c] + rv.head : 0;
         if (p >= rv.cap) p -= rv.cap;
-        const uint16_t *mv = mem + (size_t)p * D;
+        const uint16_t *mv = STAGED ? rows_l + (size_t)(live ? c : 0) * RS : mem + (size_t)p * D;
         const bool any_order_exact = (DT == VM_F16) && live && (qnorm_fast * norm64[p] < 32.0);
         double dot = 0.0;
         if (any_order_exact) {
@@ -734,7 +765,7 @@ int run_topk_kl(vm_memory *m, const ScanPlan &p, const void *queries, int Q, int
             topk_finalize_kernel<DT, KL, true><<<Q, FIN_THREADS, (size_t)m->D * 2, st>>>(
                 m->rows, m->norm64, (const uint16_t *)queries, m->d_total, m->cap, m->ring, m->D, p.q_pad, nblk_pre,
                 part_s, part_o, k, use_min, min_score, score_mode, row_stride, row_offset, out_scores, out_rows,
-                nullptr, thr_s, thr_o);
+                nullptr, thr_s, thr_o, 0);
             VM_LAUNCH_CHECK(m->ctx);
         }
         use_ts = thr_s;
@@ -744,10 +775,25 @@ int run_topk_kl(vm_memory *m, const ScanPlan &p, const void *queries, int Q, int
         VM_OK)
         return rc;
     vm_prof_scope prof(m->ctx, VM_PROF_TOPK_FINALIZE, st);
-    topk_finalize_kernel<DT, KL, false><<<Q, FIN_THREADS, (size_t)m->D * 2, st>>>(
+    size_t fin_lds = (size_t)m->D * 2;
+    int stage_rows = 0;
+    if (DT == VM_BF16) {  // + the KL candidate rows when they fit beside the kernel's static tables (csrc: STAGED)
+        const size_t with_rows = fin_lds + (size_t)KL * (m->D + 8) * 2;
+        if (with_rows <= 96 * 1024) {
+            fin_lds = with_rows;
+            stage_rows = 1;
+            if (fin_lds > 48 * 1024) {
+                hipError_t e = hipFuncSetAttribute((const void *)topk_finalize_kernel<DT, KL, false>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_lds);
+                if (e != hipSuccess)
+                    return vm_fail(m->ctx, VM_ERR_HIP, "LDS opt-in %zu: %s", fin_lds, hipGetErrorString(e));
+            }
+        }
+    }
+    topk_finalize_kernel<DT, KL, false><<<Q, FIN_THREADS, fin_lds, st>>>(
         m->rows, m->norm64, (const uint16_t *)queries, m->d_total, m->cap, m->ring, m->D, p.q_pad, p.nblk, part_s,
         part_o, k, use_min, min_score, score_mode, row_stride, row_offset, out_scores, out_rows, uncertified, nullptr,
-        nullptr);
+        nullptr, stage_rows);
     VM_LAUNCH_CHECK(m->ctx);
     return VM_OK;
 }
