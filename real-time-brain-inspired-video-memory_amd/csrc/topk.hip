@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(SCAN_THREADS)
     };
     // (single-tile scans, QT == 1, run three waves per SIMD and are HBM-bound at 5.5 TB/s without it; there the extra
     // registers and copies cost 15 %, so they keep the plain load-then-use order)
-    constexpr bool PREFETCH = QT >= 2;
+    constexpr bool PREFETCH = QT >= 2 || KL >= 32;  // KL >= 32 runs two waves per SIMD as well
     uint4 cur[LB];
     const int64_t tile0 = (int64_t)bx * nw + wave;
     if (PREFETCH && tile0 < ntiles) issue(src_of(tile0), 0, cur);
@@ -695,7 +695,7 @@ ScanPlan make_plan(const vm_memory *m, int Q, int k) {
         const char *e = getenv("VIDMEM_TOPK_BLOCKS_PER_CU");
         env_per_cu = e ? atoi(e) : 0;
     }
-    const int per_cu = env_per_cu > 0 ? env_per_cu : ((p.cfg.QT * p.cfg.KL <= 32) ? 2 : 1);
+    const int per_cu = env_per_cu > 0 ? env_per_cu : ((p.cfg.KL <= 16 && p.cfg.QT * p.cfg.KL <= 32) ? 2 : 1);
     // Row-blocks per query group.  One group (Q <= 64): as many as the chip holds, the scan is HBM-bound.  Many
     // groups: the groups already fill the chip, and FEWER row-blocks per group means more rows per lane list, so
     // the lists warm up and most scores fail the one-compare threshold test instead of paying a sorted insert.
