@@ -187,22 +187,36 @@ __device__ __forceinline__ void attend_tile_pass2(const char *kl, const char *vl
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto scores = [&](int kt, bool masked) {
-        const vec8 k0 = *reinterpret_cast<const vec8 *>(p0 + kt * 2048);
-        const vec8 k1 = *reinterpret_cast<const vec8 *>(p1 + kt * 2048);
-        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
-        a = E::mfma16(k0, qa, a);
-        a = E::mfma16(k1, qb, a);
-        if (masked) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) a[j] = (kt * 16 + 4 * h + j < T) ? a[j] : -INFINITY;
-        }
-        return a;
-    };
     auto step = [&](int ks, bool masked0, bool has1, bool masked1) {
+        // every LDS read of the step is issued up front - the K fragments of both key tiles and the eight transposed V
+        // fragments (they do not depend on P) - so one LDS latency is exposed per 32 keys instead of six
+        const char *row_lo = vrow + ks * 32 * 128;
+        const int hi_off = has1 ? 16 * 128 : 0;  // odd NT: the last half step re-reads valid rows against P = 0
+        const vec8 ka0 = *reinterpret_cast<const vec8 *>(p0 + (2 * ks) * 2048);
+        const vec8 ka1 = *reinterpret_cast<const vec8 *>(p1 + (2 * ks) * 2048);
+        const vec8 kb0 = *reinterpret_cast<const vec8 *>(p0 + (2 * ks + (has1 ? 1 : 0)) * 2048);
+        const vec8 kb1 = *reinterpret_cast<const vec8 *>(p1 + (2 * ks + (has1 ? 1 : 0)) * 2048);
+        s4v vlo[4], vhi[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            vlo[dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr)(row_lo + voff[dt]));
+            vhi[dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr)(row_lo + hi_off + voff[dt]));
+        }
         f32x4 a[2];
-        a[0] = scores(2 * ks, masked0);
-        a[1] = has1 ? scores(2 * ks + 1, masked1) : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        a[0] = E::mfma16(ka0, qa, f32x4{0.f, 0.f, 0.f, 0.f});
+        a[0] = E::mfma16(ka1, qb, a[0]);
+        a[1] = E::mfma16(kb0, qa, f32x4{0.f, 0.f, 0.f, 0.f});
+        a[1] = E::mfma16(kb1, qb, a[1]);
+        if (masked0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[0][j] = ((2 * ks) * 16 + 4 * h + j < T) ? a[0][j] : -INFINITY;
+        }
+        if (!has1) {
+            a[1] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        } else if (masked1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[1][j] = ((2 * ks + 1) * 16 + 4 * h + j < T) ? a[1][j] : -INFINITY;
+        }
         uint16_t pe[8];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -219,13 +233,9 @@ __device__ __forceinline__ void attend_tile_pass2(const char *kl, const char *vl
         }
         vec8 pf;
         __builtin_memcpy(&pf, pe, 16);
-        const char *row_lo = vrow + ks * 32 * 128;
-        const int hi_off = has1 ? 16 * 128 : 0;  // odd NT: the last half step re-reads valid rows against P = 0
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-            const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr)(row_lo + voff[dt]));
-            const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr)(row_lo + hi_off + voff[dt]));
-            const s8v av = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            const s8v av = __builtin_shufflevector(vlo[dt], vhi[dt], 0, 1, 2, 3, 4, 5, 6, 7);
             o[dt] = E::mfma16(__builtin_bit_cast(vec8, av), pf, o[dt]);
         }
     };
