@@ -88,6 +88,9 @@ def test_preprocess_identity_is_exact():
     ("bf16", 2, "quick_gelu", True, 1024, 16, 4096, 336, 14),
     ("f16", 2, "quick_gelu", True, 256, 4, 512, 64, 16),       # 17 tokens: ragged tiles everywhere
     ("bf16", 1, "gelu", False, 512, 8, 1024, 96, 16),          # 37 tokens
+    ("f16", 1, "gelu", False, 256, 4, 512, 160, 16),           # 101 tokens: 7 of 13 key tiles (masked-tile path)
+    ("bf16", 1, "quick_gelu", True, 256, 4, 512, 224, 14),     # 257 tokens: two-pass kernel, 17 of 37 key tiles
+    ("f16", 1, "gelu", False, 256, 4, 512, 240, 16),           # 226 tokens: two-pass kernel just above 13 tiles
 ])
 def test_short_stacks_match_oracle(dtype, layers, act, pre_ln, hidden, heads, mlp, image, patch):
     from vidmem import synthetic as syn
