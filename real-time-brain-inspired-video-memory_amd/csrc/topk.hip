@@ -144,6 +144,8 @@ __global__ void __launch_bounds__(SCAN_THREADS)
     // a multi-tile scan spent ~9 us per row tile waiting for three round trips.
     constexpr int LB = 8;
     const int64_t tile_step = (int64_t)nbx * nw;
+    const uint4 *qrow = qlds + r16 * chunks;  // this lane's query row of tile 0
+    const int tstride = 16 * chunks;          // uint4 units between query tiles
     auto src_of = [&](int64_t tile) {
         int64_t row = tile * 16 + r16;
         if (row > rv.n - 1) row = rv.n - 1;  // tail lanes re-read the last row; their scores are masked below
@@ -178,9 +180,12 @@ __global__ void __launch_bounds__(SCAN_THREADS)
                 if (s0 + u < ksteps) {  // ksteps is a multiple of 4; uniform branch
                     const int ci = h + 4 * (s0 + u);
                     const vec8 av = __builtin_bit_cast(vec8, cur[u]);
+                    // one swizzled address per k-step; the QT query tiles sit a wave-uniform stride apart (spelled
+                    // out: left to the compiler, the index arithmetic was ~6 VALU per LDS read, 600 per row tile)
+                    const uint4 *qp = qrow + ((ci & ~15) | ((ci ^ r16) & 15));
 #pragma unroll
                     for (int t = 0; t < QT; ++t) {
-                        const uint4 bq = qlds[(t * 16 + r16) * chunks + ((ci & ~15) | ((ci ^ r16) & 15))];
+                        const uint4 bq = qp[t * tstride];
                         acc[t] = E::mfma16(av, __builtin_bit_cast(vec8, bq), acc[t]);
                     }
                 }
