@@ -10,8 +10,9 @@ Workload = BASELINE.json configs[1]: "ViT-B/16 encoder, 4k frames (chunk_size=16
 Frames are sharded by chunk, memory rows by rank; per-GPU work is fixed as N grows ("weak").
 
 Prints ONE JSON line (rank 0).  `value` = frame embeddings per second over all GPUs, inputs resident in HBM.
-Extra objects: `roofline` (dominant kernel, HIP-event timed inside the timed region), `cpu_baseline` (the oracle
-on the host cores, bounded sample; rank 0, N=1 only), `knn` (the kNN half of the metric on a 1M x 768 index).
+Extra objects: `roofline` (dominant kernel, HIP-event timed inside the timed region) and, at N=1 only, `cpu_baseline`
+(the oracle on the host cores, bounded sample), `knn` (the kNN half of the metric on a 1M x 768 index), `streaming`
+(BASELINE configs[4]: 16 x 1080p chunks through one hipGraph) and `c3` (BASELINE configs[2]: CLIP-ViT-L/14-336 bf16).
 """
 import argparse
 import json
@@ -234,7 +235,7 @@ def main():
         out["encoder_tflops"] = specs.flops_per_frame(spec) * F / (enc_ms * 1e-3) / 1e12 if enc_ms > 0 else None
 
     # ---- kNN half of the metric: Q=16 queries/launch over a 1M x 768 index (single GPU part of every rank 0) ----
-    if rank == 0 and not args.no_knn:
+    if rank == 0 and world == 1 and not args.no_knn:
         del frame_pool
         Mk = args.knn_rows
         big = EmbeddingMemory(Mk, D, "f16", device=local_rank)
@@ -281,7 +282,7 @@ def main():
         big.close()
 
     # ---- streaming leg (BASELINE configs[4]): 16 x 1080p frames per chunk, rolling 2M-row memory, one hipGraph ------
-    if rank == 0 and not args.no_streaming:
+    if rank == 0 and world == 1 and not args.no_streaming:
         from vidmem.streaming import StreamingSession
         Ms = args.stream_rows
         ring = EmbeddingMemory(Ms, D, "f16", ring=True, device=local_rank)
@@ -327,7 +328,7 @@ def main():
         ring.close()
 
     # ---- BASELINE configs[2] leg: CLIP-ViT-L/14-336 bf16 encoder + top-20 over a 1M x 1024 bf16 index --------------
-    if rank == 0 and not args.no_c3:
+    if rank == 0 and world == 1 and not args.no_c3:
         del enc
         torch.cuda.empty_cache()
         spec3 = specs.CLIP_L14_336
