@@ -578,7 +578,8 @@ __global__ void __launch_bounds__(512, 1) gemm256p_kernel(GemmArgs g) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const f32x4 a = acc[i][p];
-                        f32x2 v01 = {a[0] + b4[i].x, a[1] + b4[i].y}, v23 = {a[2] + b4[i].z, a[3] + b4[i].w};
+                        f32x2 v01 = f32x2{a[0], a[1]} + f32x2{b4[i].x, b4[i].y};  // v_pk_add_f32
+                        f32x2 v23 = f32x2{a[2], a[3]} + f32x2{b4[i].z, b4[i].w};
                         if (EPI == EPI_GELU16) {
                             v01 = gelu_erf2(v01);
                             v23 = gelu_erf2(v23);
@@ -587,9 +588,7 @@ __global__ void __launch_bounds__(512, 1) gemm256p_kernel(GemmArgs g) {
                             v01 = f32x2{quick_gelu(v01.x), quick_gelu(v01.y)};
                             v23 = f32x2{quick_gelu(v23.x), quick_gelu(v23.y)};
                         }
-                        const uint16_t o[4] = {E::from_float(v01.x), E::from_float(v01.y), E::from_float(v23.x),
-                                               E::from_float(v23.y)};
-                        __builtin_memcpy(&pk[i], o, 8);
+                        pk[i] = make_uint2(E::pack2(v01.x, v01.y), E::pack2(v23.x, v23.y));  // v_cvt_pk_*
                     }
 #pragma unroll
                     for (int half = 0; half < 2; ++half) {

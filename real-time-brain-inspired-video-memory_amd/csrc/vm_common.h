@@ -90,6 +90,15 @@ struct vm_elem<VM_F16> {
         __builtin_memcpy(&b, &h, 2);
         return b;
     }
+    // two values -> one packed dword (lo = a): a single v_cvt_pk_f16_f32, same RNE rounding as from_float
+    static __device__ __forceinline__ uint32_t pack2(float a, float b) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const h2 v = __builtin_convertvector(f2{a, b}, h2);
+        uint32_t u;
+        __builtin_memcpy(&u, &v, 4);
+        return u;
+    }
     static __device__ __forceinline__ f32x4 mfma16(vec8 a, vec8 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
     }
@@ -110,6 +119,14 @@ struct vm_elem<VM_BF16> {
         uint16_t b;
         __builtin_memcpy(&b, &h, 2);
         return b;
+    }
+    static __device__ __forceinline__ uint32_t pack2(float a, float b) {  // v_cvt_pk_bf16_f32
+        typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const b2 v = __builtin_convertvector(f2{a, b}, b2);
+        uint32_t u;
+        __builtin_memcpy(&u, &v, 4);
+        return u;
     }
     static __device__ __forceinline__ f32x4 mfma16(vec8 a, vec8 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
