@@ -27,26 +27,6 @@ constexpr int HALF_BYTES = 128 * BK * 2;  // 128 rows x 64 k, 16 KiB
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *gbl_ptr_t;
 
-// erf-GELU with erfc(z) = (1 + a1 z + ... + a6 z^6)^-16 (Abramowitz & Stegun 7.1.28, |error| <= 3e-7 for z >= 0):
-// ~16 VALU instead of libm erff's ~40, far below the 16-bit output's rounding.  Negative inputs use erfc directly,
-// so the tail keeps its relative accuracy.
-__device__ __forceinline__ float gelu_erf(float x) {
-    const float z = fabsf(x) * 0.70710678118654752f;
-    float p = 0.0000430638f;
-    p = __builtin_fmaf(p, z, 0.0002765672f);
-    p = __builtin_fmaf(p, z, 0.0001520143f);
-    p = __builtin_fmaf(p, z, 0.0092705272f);
-    p = __builtin_fmaf(p, z, 0.0422820123f);
-    p = __builtin_fmaf(p, z, 0.0705230784f);
-    p = __builtin_fmaf(p, z, 1.0f);
-    p = p * p;
-    p = p * p;
-    p = p * p;
-    p = p * p;
-    const float erfc_z = __builtin_amdgcn_rcpf(p);  // 0 when p overflows
-    const float half_x_erfc = 0.5f * x * erfc_z;
-    return x < 0.f ? half_x_erfc : x - half_x_erfc;
-}
 // x * sigmoid(1.702 x) with one v_exp_f32 and one v_rcp_f32 (the IEEE division sequence cost ~10 more instructions per
 // element; 1 ulp of the reciprocal is far below the 16-bit output's rounding)
 __device__ __forceinline__ float quick_gelu(float x) {
@@ -54,7 +34,9 @@ __device__ __forceinline__ float quick_gelu(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
-// The same erf-GELU on two values at once: written on 2-vectors so that hipcc emits v_pk_fma_f32 / v_pk_mul_f32
+// erf-GELU with erfc(z) = (1 + a1 z + ... + a6 z^6)^-16 (Abramowitz & Stegun 7.1.28, |error| <= 3e-7 for z >= 0):
+// far cheaper than libm erff and far below the 16-bit output's rounding.  Negative inputs use erfc directly, so the
+// tail keeps its relative accuracy.  Evaluated on two values at once: written on 2-vectors so that hipcc emits v_pk_fma_f32 / v_pk_mul_f32
 // (about 10 VALU per element).  The FC1 epilogue evaluates 65,536 of these per tile; scalar, it cost as much
 // vector-ALU time as the tile's whole MFMA loop.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -108,18 +90,19 @@ __device__ __forceinline__ void epilogue_row(const GemmArgs &g, const f32x4 (&a)
     if (EPI == EPI_STORE16 || EPI == EPI_GELU16 || EPI == EPI_QGELU16) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            float v[4] = {a[i][0] + b4[i].x, a[i][1] + b4[i].y, a[i][2] + b4[i].z, a[i][3] + b4[i].w};
-            uint16_t o[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float y = v[e];
-                if (EPI == EPI_GELU16) y = gelu_erf(y);
-                if (EPI == EPI_QGELU16) y = quick_gelu(y);
-                o[e] = E::from_float(y);
+            // the same packed sequence as the 256x256 kernel's epilogue (bit-identical outputs across kernels)
+            f32x2 v01 = f32x2{a[i][0], a[i][1]} + f32x2{b4[i].x, b4[i].y};
+            f32x2 v23 = f32x2{a[i][2], a[i][3]} + f32x2{b4[i].z, b4[i].w};
+            if (EPI == EPI_GELU16) {
+                v01 = gelu_erf2(v01);
+                v23 = gelu_erf2(v23);
             }
-            uint2 pk;
-            __builtin_memcpy(&pk, o, 8);
-            *reinterpret_cast<uint2 *>(g.out16 + out16_index(g, t, fbase + 16 * i)) = pk;
+            if (EPI == EPI_QGELU16) {
+                v01 = f32x2{quick_gelu(v01.x), quick_gelu(v01.y)};
+                v23 = f32x2{quick_gelu(v23.x), quick_gelu(v23.y)};
+            }
+            *reinterpret_cast<uint2 *>(g.out16 + out16_index(g, t, fbase + 16 * i)) =
+                make_uint2(E::pack2(v01.x, v01.y), E::pack2(v23.x, v23.y));
         }
     } else if (EPI == EPI_RESID32) {
         float *orow = g.out32 + (size_t)t * g.ldo + fbase;
