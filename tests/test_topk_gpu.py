@@ -201,3 +201,24 @@ def test_sampled_cut_path_many_queries_bit_exact(M):
     want_r, want_s = cref.cosine_topk(_bits(q), _bits(m), k, dtype="f16")
     assert np.array_equal(r.cpu().numpy(), want_r)
     assert np.array_equal(s.cpu().numpy(), want_s)
+
+
+def test_many_query_groups_bit_exact():
+    """Q = 200 at k = 10: four 64-query groups in one 1-D launch (groups of a row block renumbered onto one XCD),
+    sampled cut, cross-tile prefetch, network merges - the configuration bench.py's main leg and its Q=256 kNN batch
+    run, checked row for row and bit for bit against the C oracle."""
+    rng = np.random.default_rng(33)
+    D, M, Q, k = 128, 70_000, 200, 10
+    m = torch.tensor(rng.standard_normal((M, D)), dtype=torch.float32).to(torch.float16)
+    q = torch.tensor(rng.standard_normal((Q, D)), dtype=torch.float32).to(torch.float16)
+    q[:50] = (0.6 * m[rng.integers(0, M, 50)].float() + 0.4 * q[:50].float()).to(torch.float16)
+    m[65_000] = m[12]          # a duplicate pair far apart
+    q[199] = m[12]
+    mem = _mem("f16", M, D)
+    mem.append(m)
+    s, r = mem.topk(q, k)
+    assert mem.last_uncertified == 0
+    want_r, want_s = cref.cosine_topk(_bits(q), _bits(m), k, dtype="f16")
+    assert np.array_equal(r.cpu().numpy(), want_r)
+    assert np.array_equal(s.cpu().numpy(), want_s)
+    assert r[199, :2].tolist() == [12, 65_000]
