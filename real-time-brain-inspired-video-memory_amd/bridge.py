@@ -12,7 +12,7 @@ moves ``Chunk.embedding`` around.
 
 The memory stores 16-bit rows: values are rounded ONCE on the way in (``EmbeddingMemory._as_rows``) and every list
 that leaves here holds the exact stored values as Python floats, so export -> load -> export is the identity.
-The functions only need ``memory.append / ids / meta / dim / dtype_name / graph_uuid / rows_host()``, which lets the
+The functions only need ``memory.append / id_of / meta_of / dim / dtype_name / graph_uuid / rows_host()``, which lets the
 CPU tests drive them with a host stand-in; the native binary snapshot is ``EmbeddingMemory.snapshot / restore``.
 """
 from __future__ import annotations
@@ -49,8 +49,8 @@ def chunks_for_neo4j(memory, first_row: Optional[int] = None, count: Optional[in
     lo, hi, rows = _row_span(memory, first_row, count)
     out = []
     for r, emb in zip(range(lo, hi), rows_to_lists(rows, memory.dtype_name)):
-        cid = memory.ids[r]
-        meta = memory.meta[r] or {}
+        cid = memory.id_of(r)
+        meta = memory.meta_of(r) or {}
         try:
             index = int(str(cid).split("_")[-1])
         except ValueError:
@@ -81,8 +81,8 @@ def export_nodes(memory, embedding_model: Optional[str] = None, batch_id: Option
     lo, hi, rows = _row_span(memory, None, None)
     nodes = []
     for r, emb in zip(range(lo, hi), rows_to_lists(rows, memory.dtype_name)):
-        meta = memory.meta[r] or {}
-        props = {"id": memory.ids[r], "content": meta.get("content"), "embedding": emb}
+        meta = memory.meta_of(r) or {}
+        props = {"id": memory.id_of(r), "content": meta.get("content"), "embedding": emb}
         if "time" in meta:
             props["time"] = meta["time"]
         if embedding_model is not None:

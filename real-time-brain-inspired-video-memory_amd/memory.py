@@ -36,8 +36,12 @@ class EmbeddingMemory:
         self.capacity = int(capacity)
         self.ring = bool(ring)
         self.graph_uuid = graph_uuid
-        self.ids: List[Optional[str]] = []          # row id -> chunk id (host table, reference pre_llm_injector.py:91)
-        self.meta: List[Optional[dict]] = []        # row id -> {"time":..., "content":...} for _vector_search_chunks
+        # Host tables: chunk id (reference pre_llm_injector.py:91) and {"time":..., "content":...} (for
+        # _vector_search_chunks) of row (table_base + i).  table_base stays 0 unless a ring has wrapped far enough for
+        # the slots of overwritten rows to be dropped (see _trim_tables); use id_of / meta_of for row -> entry.
+        self.ids: List[Optional[str]] = []
+        self.meta: List[Optional[dict]] = []
+        self.table_base = 0
         h = C.c_void_p()
         self.ctx.check(self.L.vm_memory_create(self.ctx.handle, self.capacity, self.dim, _lib.DTYPES[dtype],
                                                1 if ring else 0, C.byref(h)))
@@ -87,7 +91,16 @@ class EmbeddingMemory:
         t.record_stream(torch.cuda.current_stream())
         self.ids.extend(list(ids) if ids is not None else [None] * B)
         self.meta.extend(list(meta) if meta is not None else [None] * B)
+        self._trim_tables()
         return int(first.value)
+
+    def _trim_tables(self) -> None:
+        """A rolling window must not keep one table slot per row EVER appended: once a ring holds more than two
+        capacities (+1024) of slots, those of rows that have been overwritten are dropped."""
+        if self.ring and len(self.ids) > 2 * self.capacity + 1024:
+            drop = len(self.ids) - self.capacity
+            del self.ids[:drop], self.meta[:drop]
+            self.table_base += drop
 
     def sync(self) -> int:
         """Bring the host mirror (row count, id / meta tables) in line with the device counter: call after hipGraph
@@ -96,9 +109,11 @@ class EmbeddingMemory:
         total = int(self.L.vm_memory_sync(self.handle, _lib.current_stream_ptr()))
         if total < 0:
             self.ctx.check(total)
-        del self.ids[total:], self.meta[total:]
-        self.ids.extend([None] * (total - len(self.ids)))
-        self.meta.extend([None] * (total - len(self.meta)))
+        n = max(0, total - self.table_base)
+        del self.ids[n:], self.meta[n:]
+        self.ids.extend([None] * (n - len(self.ids)))
+        self.meta.extend([None] * (n - len(self.meta)))
+        self._trim_tables()
         return total
 
     def prepare_topk(self, Q: int, k: int) -> None:
@@ -109,6 +124,7 @@ class EmbeddingMemory:
         self.ctx.check(self.L.vm_memory_reset(self.handle, _lib.current_stream_ptr()))
         self.ids.clear()
         self.meta.clear()
+        self.table_base = 0
 
     def rows_tensor(self) -> torch.Tensor:
         """Zero-copy view of the searchable physical rows [min(size, capacity), D] (debug / snapshot)."""
@@ -191,7 +207,8 @@ class EmbeddingMemory:
         total = base + rows.shape[0]
         np.savez(path, rows=rows, dtype=self.dtype_name, dim=self.dim,
                  first_row_id=base, graph_uuid=self.graph_uuid or "",
-                 ids=json.dumps(self.ids[base:total]), meta=json.dumps(self.meta[base:total]))
+                 ids=json.dumps([self.id_of(r) for r in range(base, total)]),
+                 meta=json.dumps([self.meta_of(r) for r in range(base, total)]))
 
     @classmethod
     def restore(cls, path: str, capacity: Optional[int] = None, ring: bool = False, device: int = 0
@@ -209,7 +226,12 @@ class EmbeddingMemory:
         return mem
 
     def id_of(self, row: int) -> Optional[str]:
-        return self.ids[row] if 0 <= row < len(self.ids) else None
+        i = row - self.table_base
+        return self.ids[i] if 0 <= i < len(self.ids) else None
+
+    def meta_of(self, row: int) -> Optional[dict]:
+        i = row - self.table_base
+        return self.meta[i] if 0 <= i < len(self.meta) else None
 
 
 def topk_merge(ctx: "_lib.Context", scores: torch.Tensor, rows: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -101,7 +101,7 @@ class HipVectorSearch:
             for r, s in zip(rows[0].cpu().tolist(), scores[0].cpu().tolist()):
                 if r < 0:
                     continue
-                meta = self.memory.meta[r] if r < len(self.memory.meta) and self.memory.meta[r] else {}
+                meta = self.memory.meta_of(r) or {}
                 chunks.append({"id": self.memory.id_of(r), "time": meta.get("time"), "content": meta.get("content"),
                                "score": float(s), "source": "vector"})
             return chunks

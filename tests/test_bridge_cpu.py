@@ -31,6 +31,12 @@ class HostMemory:
     def rows_host(self):
         return 0, self._rows
 
+    def id_of(self, r):
+        return self.ids[r] if 0 <= r < len(self.ids) else None
+
+    def meta_of(self, r):
+        return self.meta[r] if 0 <= r < len(self.meta) else None
+
 
 def _vecs(n, d, seed=0):
     return np.random.default_rng(seed).standard_normal((n, d)).tolist()

@@ -67,3 +67,30 @@ def test_export_json_and_chunk_dict_round_trip(tmp_path):
     n, skipped = bridge.load_chunk_embeddings(again, {c["id"]: c["embedding"] for c in chunks})
     assert n == len(mem) and not skipped
     _same_answers(mem, again, q)
+
+
+def test_ring_host_tables_stay_bounded():
+    """A rolling window keeps ids / meta for the resident rows only (plus slack): after many wraps the tables are a
+    bounded suffix, id_of / meta_of still resolve every resident row, overwritten rows resolve to None, and the
+    snapshot / Neo4j shapes are unaffected."""
+    from vidmem import bridge
+    from vidmem.memory import EmbeddingMemory
+    cap, D, B = 64, 256, 48
+    mem = EmbeddingMemory(cap, D, "f16", ring=True)
+    g = torch.Generator().manual_seed(4)
+    total = 0
+    for step in range(40):                                   # 1920 rows through a 64-row ring
+        rows = torch.randn((B, D), generator=g)
+        first = mem.append(rows, ids=[f"g_{step}_{i}" for i in range(B)], meta=[{"content": f"{step}.{i}"} for i in range(B)])
+        assert first == total
+        total += B
+    assert len(mem) == total and len(mem.ids) <= 2 * cap + 1024 + B and mem.table_base > 0
+    lo = total - cap
+    assert mem.id_of(total - 1) == "g_39_47" and mem.id_of(lo) == f"g_{lo // B}_{lo % B}"
+    assert mem.meta_of(total - 1) == {"content": "39.47"} and mem.id_of(mem.table_base - 1) is None
+    q = torch.randn((3, D), generator=g)
+    s, r = mem.topk(q, 5)
+    assert (r >= lo).all() and all(mem.id_of(int(x)) is not None for x in r.flatten())
+    chunks = bridge.chunks_for_neo4j(mem)                    # resident rows only, ids intact
+    assert len(chunks) == cap and chunks[-1]["id"] == "g_39_47" and chunks[0]["index"] == lo % B
+    assert mem.sync() == total and mem.id_of(total - 1) == "g_39_47"
