@@ -138,13 +138,27 @@ const void *vm_memory_rows(const vm_memory *mem); /* device pointer to the [capa
  *   use_min_score: keep only score > min_score (after the score_mode mapping).
  * Two-stage: an fp32 MFMA scan keeps k+slack candidates per query, which are re-scored exactly.  A query whose
  * result cannot be PROVEN equal to the exhaustive answer (fp32 error bound vs the gap to the best rejected
- * row) is counted in *out_uncertified (device int32, may be NULL); run vm_topk_cosine_exact for those. */
+ * row) is counted in *out_uncertified (device int32, accumulates, may be NULL) and marked in
+ * out_query_flags[q] = 1 (device int32 [Q], rewritten for every query on every call, may be NULL).  Pass the flags
+ * to vm_topk_redo_flagged on the same stream: the reference always returns the exhaustive answer
+ * (src/components/pre_llm_injector.py:356-370), so the pair {vm_topk_cosine, vm_topk_redo_flagged} is the drop-in. */
 size_t vm_topk_workspace_bytes(const vm_memory *mem, int Q, int k);
 int vm_topk_cosine(vm_memory *mem, const void *queries, int Q, int k, int use_min_score, double min_score,
                    int score_mode, int64_t row_stride, int64_t row_offset, double *out_scores,
-                   int64_t *out_rows, int32_t *out_uncertified, void *workspace, size_t workspace_bytes,
-                   void *stream);
-/* Exhaustive fp64 version of the same contract (every pair scored exactly; slow, always exact). */
+                   int64_t *out_rows, int32_t *out_uncertified, int32_t *out_query_flags, void *workspace,
+                   size_t workspace_bytes, void *stream);
+/* Exhaustive fp64 redo of the flagged queries only (query_flags: device int32 [Q], as written by vm_topk_cosine):
+ * their rows of out_scores / out_rows are overwritten with the exhaustive answer under the same contract; the
+ * other queries are left untouched.  Row count and flags are read on the device: no host read-back, no
+ * allocation, capturable into a hipGraph, and two near-empty launches when nothing is flagged.  k <= 64.
+ * Workspace: vm_topk_redo_workspace_bytes (slice winners, 16 bytes x blocks x Q x k; a few MB). */
+size_t vm_topk_redo_workspace_bytes(const vm_memory *mem, int Q, int k);
+int vm_topk_redo_flagged(vm_memory *mem, const void *queries, int Q, int k, int use_min_score, double min_score,
+                         int score_mode, int64_t row_stride, int64_t row_offset, const int32_t *query_flags,
+                         double *out_scores, int64_t *out_rows, void *workspace, size_t workspace_bytes,
+                         void *stream);
+/* Exhaustive fp64 version of the same contract for ALL queries (every pair scored exactly; slow, always exact;
+ * workspace Q x rows x 8 bytes; sizes its grid from the host row count, so not for graph replay). */
 size_t vm_topk_exact_workspace_bytes(const vm_memory *mem, int Q, int k);
 int vm_topk_cosine_exact(vm_memory *mem, const void *queries, int Q, int k, int use_min_score,
                          double min_score, int score_mode, int64_t row_stride, int64_t row_offset,

@@ -27,7 +27,8 @@ SYMBOLS = [
     "vm_encode_workspace_bytes", "vm_encode",
     "vm_memory_create", "vm_memory_destroy", "vm_memory_append", "vm_memory_size", "vm_memory_capacity",
     "vm_memory_dim", "vm_memory_reset", "vm_memory_sync", "vm_memory_rows",
-    "vm_topk_workspace_bytes", "vm_topk_cosine", "vm_topk_exact_workspace_bytes", "vm_topk_cosine_exact",
+    "vm_topk_workspace_bytes", "vm_topk_cosine", "vm_topk_redo_workspace_bytes", "vm_topk_redo_flagged",
+    "vm_topk_exact_workspace_bytes", "vm_topk_cosine_exact",
     "vm_cosine_exact", "vm_topk_merge", "vm_profile_enable", "vm_profile_read", "vm_profile_mask",
 ]
 PROF_CATS = ["preprocess", "gemm_patch", "gemm_qkv", "gemm_act", "gemm_resid", "attention", "layernorm", "pool",
@@ -84,7 +85,9 @@ def lib() -> C.CDLL:
         "vm_memory_sync": (i64, [vp, vp]),
         "vm_memory_rows": (vp, [vp]),
         "vm_topk_workspace_bytes": (sz, [vp, i32, i32]),
-        "vm_topk_cosine": (i32, [vp, vp, i32, i32, i32, f64, i32, i64, i64, vp, vp, vp, vp, sz, vp]),
+        "vm_topk_cosine": (i32, [vp, vp, i32, i32, i32, f64, i32, i64, i64, vp, vp, vp, vp, vp, sz, vp]),
+        "vm_topk_redo_workspace_bytes": (sz, [vp, i32, i32]),
+        "vm_topk_redo_flagged": (i32, [vp, vp, i32, i32, i32, f64, i32, i64, i64, vp, vp, vp, vp, sz, vp]),
         "vm_topk_exact_workspace_bytes": (sz, [vp, i32, i32]),
         "vm_topk_cosine_exact": (i32, [vp, vp, i32, i32, i32, f64, i32, i64, i64, vp, vp, vp, sz, vp]),
         "vm_cosine_exact": (i32, [vp, vp, i32, vp, i64, i32, i32, vp, vp]),

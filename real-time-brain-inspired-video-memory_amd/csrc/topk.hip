@@ -47,27 +47,6 @@ __device__ __forceinline__ void list_insert(float (&ls)[KL], int (&lo)[KL], floa
     lo[0] = here0 ? o : lo[0];
 }
 
-struct RingView {
-    int64_t n;     // searchable rows
-    int64_t head;  // physical slot of the oldest row
-    int64_t base;  // row id of the oldest row
-    int64_t cap;
-};
-__device__ __forceinline__ RingView ring_view(int64_t total, int64_t cap, int ring) {
-    RingView v;
-    v.cap = cap;
-    if (ring && total > cap) {
-        v.n = cap;
-        v.head = total % cap;
-        v.base = total - cap;
-    } else {
-        v.n = total < cap ? total : cap;
-        v.head = 0;
-        v.base = 0;
-    }
-    return v;
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // scan
 // ---------------------------------------------------------------------------------------------------------
@@ -344,7 +323,7 @@ __global__ void __launch_bounds__(FIN_THREADS)
                          const int *__restrict__ part_o, int k, int use_min, double min_score, int score_mode,
                          int64_t row_stride, int64_t row_offset, double *__restrict__ out_scores,
                          int64_t *__restrict__ out_rows, int *__restrict__ uncertified,
-                         float *__restrict__ thr_s_out, int *__restrict__ thr_o_out, int stage_rows) {
+                         int *__restrict__ qflags, float *__restrict__ thr_s_out, int *__restrict__ thr_o_out, int stage_rows) {
     using E = vm_elem<DT>;
     __shared__ float hs[MAX_BLOCKS];
     __shared__ int ho[MAX_BLOCKS];
@@ -368,6 +347,7 @@ __global__ void __launch_bounds__(FIN_THREADS)
     if (tid == 0) {
         cnt = 0;
         nqual = 0;
+        if (!THRESH && qflags) qflags[q] = 0;  // set again below by the thread that fails to certify this query
     }
     {   // stage the query row in LDS; fp32 upper bound of |q| (gates the any-order-exact fast paths below)
         float sq = 0.f;
@@ -621,13 +601,16 @@ __global__ void __launch_bounds__(FIN_THREADS)
         }
         // certification: is the exact k-th score provably above every row that never became a candidate?
         const int kth = (k < nfin ? k : nfin) - 1;
-        if (rank == kth && uncertified) {
+        if (rank == kth && (uncertified || qflags)) {
             const bool all_rows_are_candidates = rv.n <= (int64_t)nfin;
             if (!all_rows_are_candidates && qn != 0.0) {
                 const float bound_f32 = fs[KL - 1];  // best possible fp32 score of a rejected row (x 1/||q||)
                 const double eps = 2.0 * (double)(D + 8) * 5.9604644775390625e-08;  // 2*(D+8)*2^-24
                 const double reject = (double)bound_f32 / qn + eps;
-                if (!(e > reject)) atomicAdd(uncertified, 1);
+                if (!(e > reject)) {
+                    if (uncertified) atomicAdd(uncertified, 1);
+                    if (qflags) qflags[q] = 1;
+                }
             }
         }
     }
@@ -751,7 +734,7 @@ int launch_scan_qt(vm_memory *m, const ScanPlan &p, int nblk, int64_t row_limit,
 template <int DT, int KL>
 int run_topk_kl(vm_memory *m, const ScanPlan &p, const void *queries, int Q, int k, int use_min, double min_score,
                 int score_mode, int64_t row_stride, int64_t row_offset, double *out_scores, int64_t *out_rows,
-                int *uncertified, float *part_s, int *part_o, float *thr_s, int *thr_o, hipStream_t st) {
+                int *uncertified, int *qflags, float *part_s, int *part_o, float *thr_s, int *thr_o, hipStream_t st) {
     int rc;
     const float *use_ts = nullptr;
     const int *use_to = nullptr;
@@ -770,7 +753,7 @@ int run_topk_kl(vm_memory *m, const ScanPlan &p, const void *queries, int Q, int
             topk_finalize_kernel<DT, KL, true><<<Q, FIN_THREADS, (size_t)m->D * 2, st>>>(
                 m->rows, m->norm64, (const uint16_t *)queries, m->d_total, m->cap, m->ring, m->D, p.q_pad, nblk_pre,
                 part_s, part_o, k, use_min, min_score, score_mode, row_stride, row_offset, out_scores, out_rows,
-                nullptr, thr_s, thr_o, 0);
+                nullptr, nullptr, thr_s, thr_o, 0);
             VM_LAUNCH_CHECK(m->ctx);
         }
         use_ts = thr_s;
@@ -797,8 +780,8 @@ int run_topk_kl(vm_memory *m, const ScanPlan &p, const void *queries, int Q, int
     }
     topk_finalize_kernel<DT, KL, false><<<Q, FIN_THREADS, fin_lds, st>>>(
         m->rows, m->norm64, (const uint16_t *)queries, m->d_total, m->cap, m->ring, m->D, p.q_pad, p.nblk, part_s,
-        part_o, k, use_min, min_score, score_mode, row_stride, row_offset, out_scores, out_rows, uncertified, nullptr,
-        nullptr, stage_rows);
+        part_o, k, use_min, min_score, score_mode, row_stride, row_offset, out_scores, out_rows, uncertified, qflags,
+        nullptr, nullptr, stage_rows);
     VM_LAUNCH_CHECK(m->ctx);
     return VM_OK;
 }
@@ -806,10 +789,10 @@ int run_topk_kl(vm_memory *m, const ScanPlan &p, const void *queries, int Q, int
 template <int DT>
 int run_topk(vm_memory *m, const ScanPlan &p, const void *queries, int Q, int k, int use_min, double min_score,
              int score_mode, int64_t row_stride, int64_t row_offset, double *out_scores, int64_t *out_rows,
-             int *uncertified, float *part_s, int *part_o, float *thr_s, int *thr_o, hipStream_t st) {
+             int *uncertified, int *qflags, float *part_s, int *part_o, float *thr_s, int *thr_o, hipStream_t st) {
 #define GO(KLV)                                                                                                   \
     return run_topk_kl<DT, KLV>(m, p, queries, Q, k, use_min, min_score, score_mode, row_stride, row_offset,      \
-                                out_scores, out_rows, uncertified, part_s, part_o, thr_s, thr_o, st)
+                                out_scores, out_rows, uncertified, qflags, part_s, part_o, thr_s, thr_o, st)
     switch (p.cfg.KL) {
         case 8: GO(8);
         case 16: GO(16);
@@ -829,8 +812,8 @@ extern "C" size_t vm_topk_workspace_bytes(const vm_memory *m, int Q, int k) {
 
 extern "C" int vm_topk_cosine(vm_memory *m, const void *queries, int Q, int k, int use_min_score,
                               double min_score, int score_mode, int64_t row_stride, int64_t row_offset,
-                              double *out_scores, int64_t *out_rows, int32_t *out_uncertified, void *workspace,
-                              size_t workspace_bytes, void *stream) {
+                              double *out_scores, int64_t *out_rows, int32_t *out_uncertified,
+                              int32_t *out_query_flags, void *workspace, size_t workspace_bytes, void *stream) {
     if (!m) return VM_ERR_INVALID;
     vm_ctx *ctx = m->ctx;
     if (!queries || !out_scores || !out_rows || Q <= 0 || k <= 0)
@@ -852,9 +835,10 @@ extern "C" int vm_topk_cosine(vm_memory *m, const void *queries, int Q, int k, i
     hipStream_t st = (hipStream_t)stream;
     if (m->dtype == VM_F16)
         return run_topk<VM_F16>(m, p, queries, Q, k, use_min_score, min_score, score_mode, row_stride,
-                                row_offset, out_scores, out_rows, out_uncertified, part_s, part_o, thr_s, thr_o, st);
+                                row_offset, out_scores, out_rows, out_uncertified, out_query_flags, part_s, part_o, thr_s, thr_o,
+                                st);
     return run_topk<VM_BF16>(m, p, queries, Q, k, use_min_score, min_score, score_mode, row_stride, row_offset,
-                             out_scores, out_rows, out_uncertified, part_s, part_o, thr_s, thr_o, st);
+                             out_scores, out_rows, out_uncertified, out_query_flags, part_s, part_o, thr_s, thr_o, st);
 }
 
 extern "C" int vm_topk_merge(vm_ctx *ctx, const double *scores, const int64_t *rows, int parts, int Q, int k,

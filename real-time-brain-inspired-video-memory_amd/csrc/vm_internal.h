@@ -14,3 +14,23 @@ struct vm_memory {
     int64_t *d_total;  // device: rows appended so far (drives slots under graph replay)
     int64_t h_total;   // host mirror
 };
+
+// Logical view of the (ring) row store for a device-side row count: searchable rows n, physical slot of the oldest
+// row (head), row id of the oldest row (base).  Row of age order o (0 = oldest) sits in slot (o + head) % cap.
+struct RingView {
+    int64_t n, head, base, cap;
+};
+__host__ __device__ inline RingView ring_view(int64_t total, int64_t cap, int ring) {
+    RingView v;
+    v.cap = cap;
+    if (ring && total > cap) {
+        v.n = cap;
+        v.head = total % cap;
+        v.base = total - cap;
+    } else {
+        v.n = total < cap ? total : cap;
+        v.head = 0;
+        v.base = 0;
+    }
+    return v;
+}

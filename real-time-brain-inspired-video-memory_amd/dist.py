@@ -6,7 +6,8 @@ local row r on rank g is ``r * world + g`` so the (score desc, row id asc) tie r
 
 Exchange per search (the only collectives on the path, RCCL over xGMI; backend "nccl" is RCCL on ROCm):
   1. all-gather of the step's query embeddings  [F, D] -> [world*F, D]      (24 KB per 16-frame chunk)
-  2. local cosine top-k of ALL queries over the local shard                 (csrc/topk.hip)
+  2. local cosine top-k of ALL queries over the local shard                 (csrc/topk.hip; queries the fp32 scan
+     cannot certify are redone exhaustively on the device, csrc/topk_exact.hip, so every shard's list is exact)
   3. all-gather of the candidates {fp64 score, int64 global row} [world*F, k]
   4. merge of the `world` candidate lists of this rank's own queries        (csrc/topk.hip topk_merge_kernel)
 No bulk row traffic ever crosses GPUs.  With world == 1 there is no collective and no torch.distributed import.
@@ -28,7 +29,9 @@ class ShardedRetriever:
         self.rank, self.world, self.group = int(rank), int(world), group
         if local_topk is None:
             def local_topk(q, k, stride, offset):
-                return memory.topk(q, k, row_stride=stride, row_offset=offset, check_certified=False)
+                # exhaustive answer on the local shard: the scan's uncertified queries are redone on the device
+                # (vm_topk_redo_flagged) BEFORE the candidate all-gather; no host read-back, no cross-rank branch
+                return memory.topk(q, k, row_stride=stride, row_offset=offset)
         if merge is None:
             from .memory import topk_merge
 
@@ -65,6 +68,6 @@ class ShardedRetriever:
         return out
 
     def uncertified_total(self) -> int:
-        """Queries (since the last certified call) whose fast-path answer could not be proven exhaustive."""
-        u = getattr(self.memory, "_uncert", None)
-        return int(u.item()) if u is not None else 0
+        """Local-shard queries the fast scan could not certify and the exhaustive kernel therefore redid (since the
+        memory's ``reset_uncertified``).  Informational: the returned results are exhaustive either way."""
+        return int(getattr(self.memory, "uncertified_count", 0))

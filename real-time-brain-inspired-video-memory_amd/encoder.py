@@ -115,23 +115,39 @@ class FrameEncoder:
         x = torch.nn.functional.pad(x, (0, self.patch_k - x.shape[-1]))
         return x.to(device=self.device, dtype=self.dtype).contiguous()
 
-    def encode_patches(self, patches: torch.Tensor, l2_normalise: bool = True) -> torch.Tensor:
+    def workspace_bytes(self, B: int) -> int:
+        return int(self.L.vm_encode_workspace_bytes(self.handle, int(B)))
+
+    def new_workspace(self, B: int) -> torch.Tensor:
+        """A workspace for batches of up to B frames that the CALLER owns (streaming sessions: a captured hipGraph
+        bakes the address in, so it must not be the encoder's shared, growable one)."""
+        return torch.empty(self.workspace_bytes(B), dtype=torch.uint8, device=self.device)
+
+    def encode_patches(self, patches: torch.Tensor, l2_normalise: bool = True,
+                       workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
         if patches.dtype != self.dtype or patches.shape[1:] != (self.tokens - 1, self.patch_k):
             raise ValueError(f"patches must be [B,{self.tokens - 1},{self.patch_k}] {self.dtype}")
         patches = patches.contiguous()
         B = patches.shape[0]
-        need = int(self.L.vm_encode_workspace_bytes(self.handle, B))
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        need = self.workspace_bytes(B)
+        if workspace is None:
+            # shared scratch of the eager path: calls are ordered on the current stream; a grown buffer replaces the
+            # old one, which the caching allocator hands out again only behind this stream's pending work
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            workspace = self._ws
+        elif workspace.numel() < need:
+            raise ValueError(f"caller-owned encoder workspace {workspace.numel()} < {need} bytes")
         out = torch.empty((B, self.out_dim), dtype=self.dtype, device=self.device)
         self.ctx.check(self.L.vm_encode(self.handle, C.c_void_p(patches.data_ptr()), B, C.c_void_p(out.data_ptr()),
-                                        1 if l2_normalise else 0, C.c_void_p(self._ws.data_ptr()),
-                                        self._ws.numel(), _lib.current_stream_ptr()))
+                                        1 if l2_normalise else 0, C.c_void_p(workspace.data_ptr()),
+                                        workspace.numel(), _lib.current_stream_ptr()))
         patches.record_stream(torch.cuda.current_stream())
         return out
 
-    def embed_frames(self, frames_u8: torch.Tensor, l2_normalise: bool = True) -> torch.Tensor:
-        return self.encode_patches(self.preprocess(frames_u8), l2_normalise)
+    def embed_frames(self, frames_u8: torch.Tensor, l2_normalise: bool = True,
+                     workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return self.encode_patches(self.preprocess(frames_u8), l2_normalise, workspace)
 
 
 class HipEmbedder:

@@ -46,8 +46,7 @@ class EmbeddingMemory:
         self.ctx.check(self.L.vm_memory_create(self.ctx.handle, self.capacity, self.dim, _lib.DTYPES[dtype],
                                                1 if ring else 0, C.byref(h)))
         self.handle = h
-        self._ws = None
-        self._uncert = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._scratch = TopkScratch(self.device)
 
     def close(self):
         if getattr(self, "handle", None):
@@ -117,8 +116,8 @@ class EmbeddingMemory:
         return total
 
     def prepare_topk(self, Q: int, k: int) -> None:
-        """Size the top-k workspace for (Q, k) now, so a later graph capture allocates nothing."""
-        self._workspace(int(self.L.vm_topk_workspace_bytes(self.handle, int(Q), int(k))))
+        """Size the shared top-k scratch for (Q, k) now, so a later eager call allocates nothing."""
+        self._scratch = self._scratch.fit(self, Q, k)
 
     def reset(self):
         self.ctx.check(self.L.vm_memory_reset(self.handle, _lib.current_stream_ptr()))
@@ -133,18 +132,22 @@ class EmbeddingMemory:
         return _tensor_from_ptr(ptr, (n, self.dim), self.dtype, self.device)
 
     # ------------------------------------------------------------------------------------------------------
-    def _workspace(self, nbytes: int) -> torch.Tensor:
-        if self._ws is None or self._ws.numel() < nbytes:
-            self._ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=self.device)
-        return self._ws
-
     def topk(self, queries, k: int, min_score: Optional[float] = None, score_mode: int = _lib.VM_SCORE_RAW,
-             row_stride: int = 1, row_offset: int = 0, exact: bool = False,
-             check_certified: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
-        """-> (scores [Q,k] float64, rows [Q,k] int64, -1 padded), ordered (score desc, row asc).
+             row_stride: int = 1, row_offset: int = 0, exact: bool = False, redo: bool = True,
+             scratch: Optional["TopkScratch"] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """-> (scores [Q,k] float64, rows [Q,k] int64, -1 padded), ordered (score desc, row asc): ALWAYS the
+        exhaustive answer, as the reference returns it (src/components/pre_llm_injector.py:356-370).
 
-        Fast path = fp32 MFMA scan + exact fp64 re-scoring (csrc/topk.hip).  Queries the scan cannot certify, and
-        k > 58, go through the exhaustive fp64 kernel (csrc/topk_exact.hip).  Both are GPU paths.
+        Fast path = fp32 MFMA scan + exact fp64 re-scoring (csrc/topk.hip), which marks the queries it cannot
+        certify (more exact ties than candidate slots, gaps below the fp32 bound) in a per-query flag array;
+        ``vm_topk_redo_flagged`` (csrc/topk_exact.hip) then redoes exactly those queries exhaustively on the device.
+        Both read flags and row count from device memory: no host read-back, graph-capturable.  ``redo=False`` skips
+        the second stage (measurement of the scan alone).  k > 58 and ``exact=True`` run the all-query exhaustive
+        kernel.  A query of the wrong length scores 0.0 against every row in the reference (:378-379); here it raises
+        in ``_as_rows`` unless the caller filters it (similarity.batch_similarities does).
+
+        ``scratch``: workspaces + flag / counter buffers owned by the caller (streaming sessions capture their
+        addresses into a hipGraph); default = this memory's own, used by eager calls on the current stream.
         """
         q = self._as_rows(queries)
         Q = q.shape[0]
@@ -154,27 +157,40 @@ class EmbeddingMemory:
         use_min = 0 if min_score is None else 1
         ms = 0.0 if min_score is None else float(min_score)
         if not exact and k <= 58:
-            need = int(self.L.vm_topk_workspace_bytes(self.handle, Q, k))
-            ws = self._workspace(need)
-            if check_certified:
-                self._uncert.zero_()  # otherwise the counter keeps accumulating (read it with .item() later)
+            if scratch is None:
+                scratch = self._scratch = self._scratch.fit(self, Q, k)
+            elif not scratch.fits(self, Q, k):
+                raise ValueError("caller-owned top-k scratch is too small for this (Q, k)")
             self.ctx.check(self.L.vm_topk_cosine(
                 self.handle, C.c_void_p(q.data_ptr()), Q, k, use_min, ms, int(score_mode), int(row_stride),
                 int(row_offset), C.c_void_p(scores.data_ptr()), C.c_void_p(rows.data_ptr()),
-                C.c_void_p(self._uncert.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(), st))
-            self.last_uncertified = None
-            if not check_certified:
-                return scores, rows
-            self.last_uncertified = int(self._uncert.item())  # one 4-byte readback; results are read next anyway
-            if self.last_uncertified == 0:
-                return scores, rows
+                C.c_void_p(scratch.uncert.data_ptr()), C.c_void_p(scratch.flags.data_ptr()),
+                C.c_void_p(scratch.ws.data_ptr()), scratch.ws.numel(), st))
+            if redo:
+                self.ctx.check(self.L.vm_topk_redo_flagged(
+                    self.handle, C.c_void_p(q.data_ptr()), Q, k, use_min, ms, int(score_mode), int(row_stride),
+                    int(row_offset), C.c_void_p(scratch.flags.data_ptr()), C.c_void_p(scores.data_ptr()),
+                    C.c_void_p(rows.data_ptr()), C.c_void_p(scratch.redo_ws.data_ptr()), scratch.redo_ws.numel(),
+                    st))
+            q.record_stream(torch.cuda.current_stream())
+            return scores, rows
         need = int(self.L.vm_topk_exact_workspace_bytes(self.handle, Q, k))
-        ws = self._workspace(need)
+        ws = torch.empty(max(need, 256), dtype=torch.uint8, device=self.device)
         self.ctx.check(self.L.vm_topk_cosine_exact(
             self.handle, C.c_void_p(q.data_ptr()), Q, k, use_min, ms, int(score_mode), int(row_stride),
             int(row_offset), C.c_void_p(scores.data_ptr()), C.c_void_p(rows.data_ptr()),
             C.c_void_p(ws.data_ptr()), ws.numel(), st))
+        ws.record_stream(torch.cuda.current_stream())
         return scores, rows
+
+    @property
+    def uncertified_count(self) -> int:
+        """Queries redone exhaustively since ``reset_uncertified`` on this memory's own scratch (one 4-byte
+        read-back; synchronises)."""
+        return int(self._scratch.uncert.item())
+
+    def reset_uncertified(self) -> None:
+        self._scratch.uncert.zero_()
 
     def cosine_exact(self, queries, rows) -> torch.Tensor:
         """All-pairs reference cosine [Q,S] float64 between two row sets (neither needs to be stored)."""
@@ -232,6 +248,43 @@ class EmbeddingMemory:
     def meta_of(self, row: int) -> Optional[dict]:
         i = row - self.table_base
         return self.meta[i] if 0 <= i < len(self.meta) else None
+
+
+class TopkScratch:
+    """Device buffers one stream of top-k calls needs: the scan workspace, the redo workspace, the per-query flag
+    array and the uncertified counter.  An owner keeps ONE instance per stream / captured graph: a hipGraph bakes the
+    addresses in, so a scratch a capture has seen is never re-allocated (``fit`` returns a NEW object when it has to
+    grow and leaves the old buffers to whoever still references them)."""
+
+    def __init__(self, device, Q: int = 0, k: int = 0, ws_bytes: int = 0, redo_bytes: int = 0):
+        self.Q, self.k = int(Q), int(k)
+        self.ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=device)
+        self.redo_ws = torch.empty(max(redo_bytes, 256), dtype=torch.uint8, device=device)
+        self.flags = torch.zeros(max(Q, 1), dtype=torch.int32, device=device)
+        self.uncert = torch.zeros(1, dtype=torch.int32, device=device)
+
+    @staticmethod
+    def _need(memory: "EmbeddingMemory", Q: int, k: int):
+        return (int(memory.L.vm_topk_workspace_bytes(memory.handle, int(Q), int(k))),
+                int(memory.L.vm_topk_redo_workspace_bytes(memory.handle, int(Q), int(k))))
+
+    def fits(self, memory: "EmbeddingMemory", Q: int, k: int) -> bool:
+        ws, redo = self._need(memory, Q, k)
+        return self.ws.numel() >= ws and self.redo_ws.numel() >= redo and self.flags.numel() >= Q
+
+    def fit(self, memory: "EmbeddingMemory", Q: int, k: int) -> "TopkScratch":
+        if self.fits(memory, Q, k):
+            return self
+        ws, redo = self._need(memory, Q, k)
+        new = TopkScratch(self.ws.device, max(Q, self.flags.numel()), k, max(ws, self.ws.numel()),
+                          max(redo, self.redo_ws.numel()))
+        new.uncert.copy_(self.uncert)
+        return new
+
+    @classmethod
+    def for_(cls, memory: "EmbeddingMemory", Q: int, k: int) -> "TopkScratch":
+        ws, redo = cls._need(memory, Q, k)
+        return cls(memory.device, Q, k, ws, redo)
 
 
 def topk_merge(ctx: "_lib.Context", scores: torch.Tensor, rows: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -14,7 +14,7 @@ from typing import Tuple
 import torch
 
 from .encoder import FrameEncoder
-from .memory import EmbeddingMemory
+from .memory import EmbeddingMemory, TopkScratch
 
 
 class StreamingSession:
@@ -28,6 +28,12 @@ class StreamingSession:
         self.stream = torch.cuda.Stream(device=dev)
         self._appended_by_graph = 0
         self._stager = None
+        # Everything the captured graph writes through lives in buffers THIS session owns for its whole life: the
+        # encoder workspace, the top-k workspaces, the per-query flags and the uncertified counter.  The encoder's and
+        # the memory's own scratch may be re-allocated by a later, larger eager call, and eager calls on another
+        # stream would race a replay on shared scratch.
+        self._enc_ws = encoder.new_workspace(frames_per_chunk)
+        self._scratch = TopkScratch.for_(memory, frames_per_chunk, top_k)
         with torch.cuda.stream(self.stream):
             # Warm up (code objects, kernel attributes, encoder workspace) against a scratch ring so that the user's
             # memory is not touched: a graph capture records launches without running them.
@@ -37,7 +43,6 @@ class StreamingSession:
             for _ in range(max(1, warmup)):
                 self._body(scratch)
             scratch.close()
-            memory.prepare_topk(frames_per_chunk, top_k)
             self.stream.synchronize()
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, stream=self.stream):
@@ -46,10 +51,20 @@ class StreamingSession:
         self._host_rows = len(memory)
 
     def _body(self, mem: EmbeddingMemory) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-        emb = self.enc.embed_frames(self.frames_in)
-        scores, rows = mem.topk(emb, self.k, check_certified=False)   # uncertified queries are counted on device
+        emb = self.enc.embed_frames(self.frames_in, workspace=self._enc_ws)
+        # exhaustive answers inside the graph: the scan flags what it cannot certify, the redo kernel reads the flags
+        # on the device.  The counter is zeroed per replay, so after a push it is THAT push's number of redone queries.
+        self._scratch.uncert.zero_()
+        scores, rows = mem.topk(emb, self.k, scratch=self._scratch)
         mem.append(emb)
         return emb, scores, rows
+
+    @property
+    def uncertified_last_push(self) -> int:
+        """Queries of the most recent push that the fp32 scan could not certify and the exhaustive kernel redid
+        inside the same replay (results are exhaustive either way).  Synchronises the session stream."""
+        self.stream.synchronize()
+        return int(self._scratch.uncert.item())
 
     def push(self, frames_u8: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """Copy one chunk in, replay the graph; returns views of the graph's output buffers (valid until the next

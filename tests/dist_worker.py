@@ -24,6 +24,12 @@ def main():
     queries = torch.randn((world * F, D), generator=g).to(torch.float16)
     queries[3] = rows[17]
     queries[F + 2] = rows[4001]
+    # 40 identical rows, 20 per shard (tests/test_topk_gpu.py's uncertifiable case split across two shards): each
+    # shard's scan must refuse to certify, redo exhaustively BEFORE the candidate all-gather, and the merged answer
+    # must be the lowest ten row ids, alternating shards
+    rows[1000:1040] = rows[999]
+    queries[5] = rows[999]
+    queries[F + 7] = rows[999]
 
     shard = EmbeddingMemory(M // world + 8, D, "f16")
     shard.append(rows[rank::world])                            # row r lives on rank r % world, local row r // world
@@ -34,6 +40,14 @@ def main():
     s, r = ShardedRetriever(shard, rank, world).search(mine, k)
     want_s, want_r = full.topk(mine, k)
     ok = torch.equal(r, want_r) and torch.equal(s, want_s)
+    # ... and against the ORACLE (the unsharded HIP result above is itself only a GPU path)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import cref
+    bits = lambda t: t.contiguous().view(torch.int16).cpu().numpy().view(np.uint16)
+    o_r, o_s = cref.cosine_topk(bits(mine), bits(rows), k, dtype="f16")
+    ok = ok and np.array_equal(r.cpu().numpy(), o_r) and np.array_equal(s.cpu().numpy(), o_s)
+    tie_q = 5 if rank == 0 else 7
+    ok = ok and r[tie_q].tolist() == list(range(999, 999 + k)) and shard.uncertified_count >= 1
     # the planted duplicates: rows 17 and 4001 tie exactly, the lower global row id comes first
     if rank == 0:
         ok = ok and r[3, :2].tolist() == [17, 4001]

@@ -56,3 +56,27 @@ def test_numpy_topk_equals_pure_python_loop(seed, q, m, k, dup, zero):
         assert [int(c[1:]) for c, _ in lst] == rows[qi, :n].tolist()
         assert [s for _, s in lst] == sc[qi, :n].tolist()
         assert (rows[qi, n:] == -1).all()
+
+
+def test_bench_launches_itself_for_n_gt_1():
+    """`python bench.py --gpus 2` with no launcher must start two ranks as child processes, rendezvous on 127.0.0.1
+    with a free port, relay rank 0's single JSON line and exit 0 (it used to raise SystemExit).  --dry-run
+    keeps the ranks on the CPU (gloo) so this runs without a GPU; the measured path differs only after the launch."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "3"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3
+    # and a world-size mismatch under an external launcher is refused, not silently accepted
+    env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], cwd=root,
+                         env=env2, capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0

@@ -55,7 +55,7 @@ def test_streaming_graph_matches_eager_and_oracle():
         lo = max(0, allrows.shape[0] - cap)
         want_r, want_s = cref.cosine_topk(_bits(emb), _bits(allrows[lo:]), k, dtype="f16")
         want_r = np.where(want_r >= 0, want_r + lo, -1)
-        assert int(mem._uncert.item()) == 0
+        assert sess.uncertified_last_push == 0
         assert np.array_equal(rows.cpu().numpy(), want_r)
         assert np.array_equal(scores.cpu().numpy(), want_s)
         hist.append(emb.clone())
@@ -71,3 +71,64 @@ def test_streaming_graph_matches_eager_and_oracle():
     assert np.array_equal(s_e.cpu().numpy(), want_s)
     first = mem.append(seed_rows[:2], ids=["a", "b"])
     assert first == 40 + 4 * B and mem.id_of(first + 1) == "b"
+
+
+def test_streaming_redoes_uncertified_queries_inside_the_replay():
+    """A chunk of IDENTICAL frames appends 16 exact duplicates per push: after three pushes a query has more exact
+    ties than candidate slots (KL = 16 at k = 10), the scan cannot certify it, and the graph's own redo kernel must
+    return the reference answer (lowest row ids first) - per-push counter > 0, results equal to the C oracle."""
+    from vidmem import specs, synthetic as syn
+    from vidmem.encoder import FrameEncoder
+    from vidmem.memory import EmbeddingMemory
+    from vidmem.streaming import StreamingSession
+    spec = dict(specs.VIT_B16_224, layers=1)
+    enc = FrameEncoder(spec, syn.encoder_weights(spec, seed=5), "f16")
+    B, cap, k = 16, 256, 10
+    mem = EmbeddingMemory(cap, 768, "f16", ring=True)
+    seed_rows = torch.from_numpy(syn.unit_rows(3, "seed", 40, 768)).to(torch.float16)
+    mem.append(seed_rows)
+    sess = StreamingSession(enc, mem, B, 224, 224, top_k=k, warmup=1)
+    one = torch.from_numpy(syn.frames_u8(7, 1, 224, 224)).cuda()
+    frames = one.expand(B, -1, -1, -1).contiguous()
+    hist = [seed_rows.cuda()]
+    counts = []
+    for step in range(4):
+        emb, scores, rows = sess.push(frames)
+        counts.append(sess.uncertified_last_push)
+        allrows = torch.cat(hist)
+        want_r, want_s = cref.cosine_topk(_bits(emb), _bits(allrows), k, dtype="f16")
+        assert np.array_equal(rows.cpu().numpy(), want_r), step
+        assert np.array_equal(scores.cpu().numpy(), want_s), step
+        hist.append(emb.clone())
+    assert counts[0] == 0 and counts[-1] == B      # 48 stored duplicates > 16 candidate slots: every query redone
+
+
+def test_session_survives_larger_eager_calls_on_the_same_encoder_and_memory():
+    """The captured graph writes through the SESSION's workspaces: a larger eager batch that re-allocates the
+    encoder's / memory's shared scratch must not disturb later replays (stale-pointer use-after-free)."""
+    from vidmem import specs, synthetic as syn
+    from vidmem.encoder import FrameEncoder
+    from vidmem.memory import EmbeddingMemory
+    from vidmem.streaming import StreamingSession
+    spec = dict(specs.VIT_B16_224, layers=1)
+    enc = FrameEncoder(spec, syn.encoder_weights(spec, seed=5), "f16")
+    B, cap, k = 16, 512, 5
+    mem = EmbeddingMemory(cap, 768, "f16", ring=True)
+    seed_rows = torch.from_numpy(syn.unit_rows(3, "seed", 100, 768)).to(torch.float16)
+    mem.append(seed_rows)
+    sess = StreamingSession(enc, mem, B, 224, 224, top_k=k, warmup=1)
+    f0 = torch.from_numpy(syn.frames_u8(200, B, 224, 224)).cuda()
+    emb0, s0, r0 = [t.clone() for t in sess.push(f0)]
+    torch.cuda.synchronize()
+    big = torch.from_numpy(syn.frames_u8(201, 96, 224, 224)).cuda()
+    e_big = enc.embed_frames(big)                     # grows the encoder's shared workspace
+    mem.topk(e_big, 40)                               # grows the memory's shared top-k scratch
+    junk = [torch.full((1 << 22,), 0x7F, dtype=torch.uint8, device="cuda") for _ in range(8)]   # reuse freed blocks
+    f1 = torch.from_numpy(syn.frames_u8(202, B, 224, 224)).cuda()
+    emb1, s1, r1 = sess.push(f1)
+    torch.cuda.synchronize()
+    assert torch.equal(emb1, enc.embed_frames(f1))
+    allrows = torch.cat([seed_rows.cuda(), emb0])
+    want_r, want_s = cref.cosine_topk(_bits(emb1), _bits(allrows), k, dtype="f16")
+    assert np.array_equal(r1.cpu().numpy(), want_r) and np.array_equal(s1.cpu().numpy(), want_s)
+    del junk

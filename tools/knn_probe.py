@@ -15,11 +15,11 @@ for lo in range(0, M, 250_000):
     x = torch.randn((n, D), generator=g, device="cuda"); mem.append((x / x.norm(dim=1, keepdim=True)).to(td))
 for Q in (16, 64, 256):
     q = torch.randn((Q, D), generator=g, device="cuda").to(td)
-    for _ in range(3): mem.topk(q, k, check_certified=False)
+    for _ in range(3): mem.topk(q, k)
     torch.cuda.synchronize(); mem.ctx.profile_enable(512)
     t0 = time.perf_counter()
-    for _ in range(50): mem.topk(q, k, check_certified=False)
+    for _ in range(50): mem.topk(q, k)
     torch.cuda.synchronize(); dtm = (time.perf_counter() - t0) / 50
     p = mem.ctx.profile_read(); mem.ctx.profile_enable(0)
     sc, fi = p["topk_scan"][0] / 50, p["topk_finalize"][0] / 50
-    print(f"D={D} {dt} k={k} Q={Q}: launch {dtm*1e3:.3f} ms, scan {sc:.3f} ms ({M*D*2/sc/1e6:.0f} GB/s), finalize {fi:.3f} ms, {Q/dtm:.0f} q/s, uncert {int(mem._uncert.item())}")
+    print(f"D={D} {dt} k={k} Q={Q}: launch {dtm*1e3:.3f} ms, scan {sc:.3f} ms ({M*D*2/sc/1e6:.0f} GB/s), finalize {fi:.3f} ms, {Q/dtm:.0f} q/s, uncert {mem.uncertified_count}")
