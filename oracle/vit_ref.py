@@ -10,12 +10,14 @@ this oracle instead (tests/golden/make_vit_golden.py, run in the authoring conta
     build-generated weights;
   * its outputs on seeded inputs are committed as golden vectors under tests/golden/.
 
-Two modes:
+Modes:
   quant=None        plain fp32 forward (the "what the model means" answer)
   quant="f16"/"bf16" same forward with a round-to-dtype at exactly the points where the HIP path stores a
-                    16-bit value (weights, pixels, patch-embed rows, LN outputs, QKV, softmax numerators, context,
-                    attention-projection and FC2 outputs, GELU output, final embedding) - fp32 everywhere else,
-                    like the kernels' accumulators and the residual stream.
+                    16-bit value (POINTS below) - fp32 everywhere else, like the kernels' accumulators and the
+                    residual stream.  With quant="bf16" the three points that are NOT matrix operands (patch rows,
+                    the two residual-branch outputs) are rounded to fp16, as the device stores them (DEVICE_POINTS).
+  quant={point: dtype} rounds only the named points, each to its own dtype: how tests/golden/bf16_floor.py prices
+                    every storage point on its own.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
 """
@@ -51,9 +53,31 @@ def _torch_dtype(quant: Optional[str]):
     return {None: None, "f16": torch.float16, "bf16": torch.bfloat16}[quant]
 
 
-def _q(x: torch.Tensor, quant: Optional[str]) -> torch.Tensor:
-    dt = _torch_dtype(quant)
-    return x if dt is None else x.to(dt).to(torch.float32)
+# every place the HIP path stores a 16-bit value
+POINTS = ("weights", "pixels", "patch", "ln", "qkv", "probs", "ctx", "proj_out", "act", "fc2_out", "head_in", "out")
+# matrix-unit operands must be in the encoder's dtype; the other three are only ever added to the fp32 residual
+# stream by a vector kernel and are stored as fp16 whatever the encoder's dtype (csrc/gemm.hip EPI_DELTA16)
+OPERAND_POINTS = ("weights", "pixels", "ln", "qkv", "probs", "ctx", "act", "head_in")
+DELTA_POINTS = ("patch", "proj_out", "fc2_out")
+
+
+def device_points(dtype: Optional[str]):
+    """{point: dtype} of the HIP path for an encoder of `dtype` (None -> no rounding anywhere)."""
+    if dtype is None:
+        return {}
+    d = {p: dtype for p in POINTS}
+    for p in DELTA_POINTS:
+        d[p] = "f16"
+    return d
+
+
+def _rounder(quant):
+    table = device_points(quant) if (quant is None or isinstance(quant, str)) else dict(quant)
+
+    def q(x: torch.Tensor, point: str) -> torch.Tensor:
+        dt = _torch_dtype(table.get(point))
+        return x if dt is None else x.to(dt).to(torch.float32)
+    return q
 
 
 def _layernorm(x, g, b, eps):
@@ -83,16 +107,17 @@ def vit_forward_ref(spec: Dict, w: Dict[str, np.ndarray], pixels_chw, quant: Opt
                     l2_normalise: bool = True, return_tokens: bool = False):
     """pixels_chw: [B,3,S,S] float (already normalised).  Returns [B, D] fp32 numpy (D = proj_dim or hidden)."""
     t = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float32)
-    qw = lambda a: _q(t(a), quant)  # GEMM weights are stored 16-bit on the device
+    q_ = _rounder(quant)
+    qw = lambda a: q_(t(a), "weights")  # GEMM weights are stored 16-bit on the device
     H, heads, L = spec["hidden"], spec["heads"], spec["layers"]
     hd = H // heads
-    x = _q(t(pixels_chw), quant)
+    x = q_(t(pixels_chw), "pixels")
     B = x.shape[0]
     patches = patchify(x, spec["patch"])  # [B,P,K]
     tok = patches @ qw(w["patch_w"]).T
     if spec["patch_bias"]:
         tok = tok + t(w["patch_b"])
-    tok = _q(tok, quant)  # the patch GEMM stores 16-bit rows; pos / cls are added in fp32 afterwards
+    tok = q_(tok, "patch")  # the patch GEMM stores 16-bit rows; pos / cls are added in fp32 afterwards
     cls = t(w["cls"]).reshape(1, 1, H).expand(B, 1, H)
     x = torch.cat([cls, tok], dim=1) + t(w["pos"]).unsqueeze(0)  # fp32 residual stream
     if spec["pre_ln"]:
@@ -101,8 +126,8 @@ def vit_forward_ref(spec: Dict, w: Dict[str, np.ndarray], pixels_chw, quant: Opt
     scale = 1.0 / math.sqrt(hd)
     for l in range(L):
         p = lambda n: w[f"l{l}.{n}"]
-        h = _q(_layernorm(x, t(p("ln1_g")), t(p("ln1_b")), spec["ln_eps"]), quant)
-        qkv = _q(h @ qw(p("qkv_w")).T + t(p("qkv_b")), quant)  # [B,N,3H]
+        h = q_(_layernorm(x, t(p("ln1_g")), t(p("ln1_b")), spec["ln_eps"]), "ln")
+        qkv = q_(h @ qw(p("qkv_w")).T + t(p("qkv_b")), "qkv")  # [B,N,3H]
         q, k, v = qkv.split(H, dim=-1)
         q = q.reshape(B, N, heads, hd).transpose(1, 2)
         k = k.reshape(B, N, heads, hd).transpose(1, 2)
@@ -111,18 +136,18 @@ def vit_forward_ref(spec: Dict, w: Dict[str, np.ndarray], pixels_chw, quant: Opt
         s = s - s.max(dim=-1, keepdim=True).values
         e = torch.exp(s)
         den = e.sum(dim=-1, keepdim=True)  # fp32 sum of the unquantised numerators
-        ctx = (_q(e, quant) @ v) / den
-        ctx = _q(ctx.transpose(1, 2).reshape(B, N, H), quant)
-        x = x + _q(ctx @ qw(p("proj_w")).T + t(p("proj_b")), quant)  # 16-bit branch output, fp32 residual
-        h = _q(_layernorm(x, t(p("ln2_g")), t(p("ln2_b")), spec["ln_eps"]), quant)
-        a = _q(_act(h @ qw(p("fc1_w")).T + t(p("fc1_b")), spec["act"]), quant)
-        x = x + _q(a @ qw(p("fc2_w")).T + t(p("fc2_b")), quant)
+        ctx = (q_(e, "probs") @ v) / den
+        ctx = q_(ctx.transpose(1, 2).reshape(B, N, H), "ctx")
+        x = x + q_(ctx @ qw(p("proj_w")).T + t(p("proj_b")), "proj_out")  # 16-bit branch output, fp32 residual
+        h = q_(_layernorm(x, t(p("ln2_g")), t(p("ln2_b")), spec["ln_eps"]), "ln")
+        a = q_(_act(h @ qw(p("fc1_w")).T + t(p("fc1_b")), spec["act"]), "act")
+        x = x + q_(a @ qw(p("fc2_w")).T + t(p("fc2_b")), "fc2_out")
     if return_tokens:
         return _layernorm(x, t(w["ln_g"]), t(w["ln_b"]), spec["ln_eps"]).numpy()
     pooled = _layernorm(x[:, 0], t(w["ln_g"]), t(w["ln_b"]), spec["ln_eps"])
     if spec.get("proj_dim", 0):
-        pooled = _q(pooled, quant) @ qw(w["proj_w"]).T
+        pooled = q_(pooled, "head_in") @ qw(w["proj_w"]).T
     if l2_normalise:
         n = torch.sqrt((pooled * pooled).sum(dim=-1, keepdim=True))
         pooled = pooled / torch.clamp(n, min=1e-12)
-    return _q(pooled, quant).numpy()
+    return q_(pooled, "out").numpy()

@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(256) resid_layernorm_kernel(float *__restrict_
         if (delta16) {
             const uint16_t *dr = delta16 + (size_t)row * H;
 #pragma unroll
-            for (int i = 0; i < VPL; ++i) d[r][i] = load4_16<DT>(dr + 4 * (lane + 64 * i));
+            for (int i = 0; i < VPL; ++i) d[r][i] = load4_16<VM_F16>(dr + 4 * (lane + 64 * i));  // EPI_DELTA16: always fp16
         }
     }
     float4 g4[VPL], b4[VPL];
@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(256) embed_kernel(const uint16_t *__restrict__
         if (tok == 0)
             e4 = reinterpret_cast<const float4 *>(cls)[c];
         else
-            e4 = load4_16<DT>(patch16 + ((size_t)frame * (T - 1) + tok - 1) * H + 4 * c);
+            e4 = load4_16<VM_F16>(patch16 + ((size_t)frame * (T - 1) + tok - 1) * H + 4 * c);  // EPI_DELTA16 rows
         v[i] = make_float4(e4.x + p4.x, e4.y + p4.y, e4.z + p4.z, e4.w + p4.w);
     }
     if (pre_ln) {
@@ -187,7 +187,7 @@ __global__ void __launch_bounds__(256) pool_kernel(const float *__restrict__ x, 
     };
     float s = 0.f;
     for (int i = tid; i < H; i += 256) {
-        const float v = row[i] + E::to_float(drow[i]);
+        const float v = row[i] + vm_elem<VM_F16>::to_float(drow[i]);  // EPI_DELTA16: always fp16
         y[i] = v;
         s += v;
     }
@@ -499,7 +499,7 @@ extern "C" int vm_encode(vm_encoder *e, const void *patches, int B, void *out_em
         };
         // patch embedding: [nb*P, patch_k] x [H, patch_k]^T (+bias) -> 16-bit rows; then x32 = rows + pos (+cls) [+pre-LN]
         if ((rc = gemm16((const uint16_t *)patches + (size_t)b0 * P * e->patch_k, e->patch_k, e->patch_w, e->patch_b,
-                         ws.d16, nb * P, H, e->patch_k, EPI_STORE16, VM_PROF_GEMM_PATCH)) != VM_OK) return rc;
+                         ws.d16, nb * P, H, e->patch_k, EPI_DELTA16, VM_PROF_GEMM_PATCH)) != VM_OK) return rc;
         if ((rc = vm_embed(ctx, dt, ws.d16, e->cls, e->pos, e->pre_g, e->pre_b, d.ln_eps, d.pre_ln, ws.x32, nb, T, H,
                            st)) != VM_OK) return rc;
         const uint16_t *delta = nullptr;  // 16-bit output of the previous residual branch, not yet added to x32
@@ -511,10 +511,10 @@ extern "C" int vm_encode(vm_encoder *e, const void *patches, int B, void *out_em
             g_head_major = 0;
             if (rc != VM_OK) return rc;
             if ((rc = vm_attention(ctx, dt, ws.qkv16, ws.a16, nb, T, d.heads, st)) != VM_OK) return rc;
-            if ((rc = gemm16(ws.a16, H, w.proj_w, w.proj_b, ws.d16, rows, H, H, EPI_STORE16, VM_PROF_GEMM_RESID)) != VM_OK) return rc;
+            if ((rc = gemm16(ws.a16, H, w.proj_w, w.proj_b, ws.d16, rows, H, H, EPI_DELTA16, VM_PROF_GEMM_RESID)) != VM_OK) return rc;
             if ((rc = vm_resid_layernorm(ctx, dt, ws.x32, ws.d16, w.ln2_g, w.ln2_b, d.ln_eps, ws.a16, rows, H, st)) != VM_OK) return rc;
             if ((rc = gemm16(ws.a16, H, w.fc1_w, w.fc1_b, ws.mlp16, rows, d.mlp, H, act_epi, VM_PROF_GEMM_ACT)) != VM_OK) return rc;
-            if ((rc = gemm16(ws.mlp16, d.mlp, w.fc2_w, w.fc2_b, ws.d16, rows, H, d.mlp, EPI_STORE16, VM_PROF_GEMM_RESID)) != VM_OK) return rc;
+            if ((rc = gemm16(ws.mlp16, d.mlp, w.fc2_w, w.fc2_b, ws.d16, rows, H, d.mlp, EPI_DELTA16, VM_PROF_GEMM_RESID)) != VM_OK) return rc;
             delta = ws.d16;
         }
         uint16_t *dst = (uint16_t *)out_emb + (size_t)b0 * e->out_dim;

@@ -83,11 +83,11 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
 // serialising on one s_waitcnt each.
 template <int DT, int EPI, int NI>
 __device__ __forceinline__ void epilogue_row(const GemmArgs &g, const f32x4 (&a)[NI], int t, int fbase) {
-    using E = vm_elem<DT>;
+    using E = vm_elem<(EPI == EPI_DELTA16) ? VM_F16 : DT>;  // output element type
     float4 b4[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) b4[i] = *reinterpret_cast<const float4 *>(g.bias + fbase + 16 * i);
-    if (EPI == EPI_STORE16 || EPI == EPI_GELU16 || EPI == EPI_QGELU16) {
+    if (EPI == EPI_STORE16 || EPI == EPI_DELTA16 || EPI == EPI_GELU16 || EPI == EPI_QGELU16) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             // the same packed sequence as the 256x256 kernel's epilogue (bit-identical outputs across kernels)
@@ -333,7 +333,9 @@ __global__ void __launch_bounds__(512, 1) gemm256p_kernel(GemmArgs g) {
     using vec8 = typename E::vec8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // vector-memory operations an epilogue leaves behind the last LDS-DMA (its stores; loads are consumed before)
-    constexpr int EPI_STORES = (EPI == EPI_STORE16 || EPI == EPI_GELU16 || EPI == EPI_QGELU16) ? 16 : 32;
+    constexpr bool OUT16 = EPI == EPI_STORE16 || EPI == EPI_DELTA16 || EPI == EPI_GELU16 || EPI == EPI_QGELU16;
+    using EO = vm_elem<(EPI == EPI_DELTA16) ? VM_F16 : DT>;  // output element type
+    constexpr int EPI_STORES = OUT16 ? 16 : 32;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -551,7 +553,7 @@ __global__ void __launch_bounds__(512, 1) gemm256p_kernel(GemmArgs g) {
                 for (int i = 0; i < 8; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
-            } else if (EPI == EPI_STORE16 || EPI == EPI_GELU16 || EPI == EPI_QGELU16) {
+            } else if (OUT16) {
                 // 2 KiB of wave-private scratch each in the spare LDS behind the bias table: 8 token rows per pass
                 char *scratch = smem + 8 * HALF_BYTES + ((g.N * 4 + 15) & ~15) + (wr * 4 + wc) * 2048;
                 const int fw = f0 + wr * 128;
@@ -576,7 +578,7 @@ __global__ void __launch_bounds__(512, 1) gemm256p_kernel(GemmArgs g) {
                             v01 = f32x2{quick_gelu(v01.x), quick_gelu(v01.y)};
                             v23 = f32x2{quick_gelu(v23.x), quick_gelu(v23.y)};
                         }
-                        pk[i] = make_uint2(E::pack2(v01.x, v01.y), E::pack2(v23.x, v23.y));  // v_cvt_pk_*
+                        pk[i] = make_uint2(EO::pack2(v01.x, v01.y), EO::pack2(v23.x, v23.y));  // v_cvt_pk_*
                     }
 #pragma unroll
                     for (int half = 0; half < 2; ++half) {
@@ -613,8 +615,7 @@ __global__ void __launch_bounds__(512, 1) gemm256p_kernel(GemmArgs g) {
         if (!has_next) break;
         {   // how many stores did this wave's epilogue leave in the pipe?  exact only for a full 16-bit tile
             const int tm_done = tile / tiles_n;
-            const bool full = ((tm_done << 8) + 256 <= M) &&
-                              (EPI == EPI_STORE16 || EPI == EPI_GELU16 || EPI == EPI_QGELU16) && !(ABL & 24);
+            const bool full = ((tm_done << 8) + 256 <= M) && OUT16 && !(ABL & 24);
             ep = full ? 1 : 2;
         }
         prestaged = do_prestage;
@@ -799,6 +800,9 @@ int launch(vm_ctx *ctx, const GemmArgs &g, int epi, hipStream_t st) {
     vm_prof_scope prof(ctx, g.prof_cat, st);
     switch (epi) {
         case EPI_STORE16: return launch_epi<DT, EPI_STORE16>(ctx, g, st);
+        case EPI_DELTA16:  // identical to STORE16 for an fp16 encoder: no second instantiation
+            if (DT == VM_F16) return launch_epi<DT, EPI_STORE16>(ctx, g, st);
+            return launch_epi<DT, EPI_DELTA16>(ctx, g, st);
         case EPI_GELU16: return launch_epi<DT, EPI_GELU16>(ctx, g, st);
         case EPI_QGELU16: return launch_epi<DT, EPI_QGELU16>(ctx, g, st);
         case EPI_RESID32: return launch_epi<DT, EPI_RESID32>(ctx, g, st);

@@ -7,7 +7,11 @@ enum {
     EPI_GELU16 = 1,   // out16 = gelu_erf(acc + bias)
     EPI_QGELU16 = 2,  // out16 = x * sigmoid(1.702 x)
     EPI_RESID32 = 3,  // out32[t, f] += acc + bias           (fp32 residual stream, in place)
-    EPI_PATCH = 4     // out32[frame*T + 1 + p, f] = acc + bias + pos[1 + p, f]   (patch embedding)
+    EPI_PATCH = 4,    // out32[frame*T + 1 + p, f] = acc + bias + pos[1 + p, f]   (patch embedding)
+    EPI_DELTA16 = 5   // out16 = fp16(acc + bias) WHATEVER the operand dtype: a residual-branch output (patch rows,
+                      // attention projection, FC2) is never a matrix operand - the LayerNorm / embed / pool kernels
+                      // add it to the fp32 residual stream - so a bf16 encoder stores it with fp16's 11 bits
+                      // (tests/golden/bf16_floor.py: 5.8e-3 -> 5.1e-3 on CLIP-L/14-336).  Same as STORE16 for fp16.
 };
 
 struct GemmArgs {

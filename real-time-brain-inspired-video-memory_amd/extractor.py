@@ -1,18 +1,30 @@
 """FrameEmbeddingExtractor: drop-in for the reference's VLMExtractor on the frame-embedding path.
 
 Mirrors ``VLMExtractor`` (src/pipeline/vlm_extractor.py):
-  * ctor takes the pipeline config (only ``config.video.chunk_size_seconds`` / ``frames_per_chunk`` are read, :38,:101);
+  * ``FrameEmbeddingExtractor(config)`` - constructible from the pipeline config ALONE, like ``VLMExtractor(config)``
+    (:19-23; caller src/cli/main.py:28).  It reads ``config.video.chunk_size_seconds`` / ``frames_per_chunk`` (:38,:101)
+    and the two new sections ``config.encoder`` / ``config.memory`` (config.py: which encoder stands where the remote
+    VLM was, how big the HBM-resident memory is); a reference ``PipelineConfig`` without those sections gets their
+    defaults.  ``FrameEmbeddingExtractor(config, encoder, memory)`` still accepts ready-made objects (shared memory,
+    tests).
   * ``async process_video(video_path, output_path) -> str`` runs the same serial chunk loop (:44-74) with the same
     integers: chunk_size_frames = int(chunk_size_seconds * fps) (:38), total_chunks = max(1, int(total/chunk)) (:39),
-    frame picks np.linspace(start, end-1, n, dtype=int) (:107), downscale to 720 rows when taller (:114-116), label
-    "MM:SS-MM:SS" (:57-59), and writes the same JSON (:77-88) - ``content`` carries a short placeholder and the new
-    fields ``embedding_rows`` / ``similar`` carry what the hot path produced for the chunk.
+    frame picks np.linspace(start, end-1, n, dtype=int) (:107), label "MM:SS-MM:SS" (:57-59), and writes the same JSON
+    (:77-88) - ``content`` carries a short placeholder and the new fields ``embedding_rows`` / ``similar`` carry what
+    the hot path produced for the chunk - and the same timing file ``metrics/vlm_<run_id>.json`` (:73,:91; metrics.py).
   * where the reference POSTs JPEGs to a remote VLM (:121-185), this encodes the frames on the GPU, retrieves the top-k
     most similar stored frames and appends the new embeddings to the memory.
 
+ONE deliberate deviation, decided here and nowhere else: the reference shrinks frames taller than 720 rows with
+``cv2.resize`` before JPEG-encoding them (:114-116) - a payload optimisation for the HTTP call.  This path has no
+payload: the preprocess kernel resamples the ORIGINAL frame to the encoder's input size in one bilinear pass
+(csrc/context.hip), which is both cheaper and closer to the source pixels than resize -> resize.  For sources of more
+than 720 rows the encoder input therefore differs from what a 720-row intermediate would give; the reference defines
+no encoder input at all, so nothing is pinned either way
+(tests/test_frames_oracle.py::test_tall_frames_are_not_downscaled_on_the_host).
+
 Frame sources: an OpenCV-readable video when ``cv2`` is importable (it is NOT installed in the build image), or an
 ``.npy`` / ``.npz`` stack of uint8 BGR frames ``[N,H,W,3]`` (``.npz``: arrays ``frames`` and optional ``fps``).
-Frame decode is the next row of the scope table, not part of this round's GPU path.
 """
 from __future__ import annotations
 
@@ -24,8 +36,12 @@ from typing import Any, List, Optional, Tuple
 import numpy as np
 import torch
 
+from . import config as cfgmod
 from .encoder import FrameEncoder
 from .memory import EmbeddingMemory
+from .metrics import MetricsTracker, get_logger
+
+logger = get_logger("vidmem.extractor")
 
 
 class _ArraySource:
@@ -84,28 +100,59 @@ def chunk_plan(fps: float, total_frames: int, chunk_size_seconds: float, frames_
     return total_chunks, plan
 
 
+def build_encoder(enc_cfg) -> FrameEncoder:
+    """``config.encoder`` -> FrameEncoder.  No checkpoint can be fetched offline and the reference names no vision
+    model (config/base_config.yaml:9 says only ``qwen-vlm``): ``weights`` is an .npz of named fp32 arrays
+    (synthetic.encoder_weight_shapes), otherwise seeded synthetic weights of the architecture."""
+    from . import specs, synthetic
+    spec = specs.SPECS[enc_cfg.arch]
+    if enc_cfg.weights:
+        z = np.load(enc_cfg.weights, allow_pickle=False)
+        weights = {k: z[k] for k in z.files}
+        missing = set(synthetic.encoder_weight_shapes(spec)) - set(weights)
+        if missing:
+            raise ValueError(f"{enc_cfg.weights}: missing weight arrays {sorted(missing)[:4]}...")
+    else:
+        weights = synthetic.encoder_weights(spec, seed=int(enc_cfg.seed))
+    return FrameEncoder(spec, weights, dtype=enc_cfg.dtype, device=int(enc_cfg.device))
+
+
+def build_memory(mem_cfg, encoder: FrameEncoder) -> EmbeddingMemory:
+    import os
+    dtype = mem_cfg.dtype or encoder.dtype_name
+    if mem_cfg.snapshot and os.path.exists(mem_cfg.snapshot):
+        return EmbeddingMemory.restore(mem_cfg.snapshot, capacity=int(mem_cfg.capacity), ring=bool(mem_cfg.ring),
+                                       device=encoder.device.index or 0)
+    return EmbeddingMemory(int(mem_cfg.capacity), encoder.out_dim, dtype, ring=bool(mem_cfg.ring),
+                           device=encoder.device.index or 0)
+
+
 class FrameEmbeddingExtractor:
-    def __init__(self, config: Any, encoder: FrameEncoder, memory: EmbeddingMemory, top_k: int = 5,
-                 stager_factory=None):
+    def __init__(self, config: Any, encoder: Optional[FrameEncoder] = None, memory: Optional[EmbeddingMemory] = None,
+                 top_k: Optional[int] = None, stager_factory=None):
         self.config = config
-        self.encoder = encoder
-        self.memory = memory
-        self.top_k = top_k
+        enc_cfg = cfgmod.section(config, "encoder", cfgmod.ENCODER_DEFAULTS)
+        mem_cfg = cfgmod.section(config, "memory", cfgmod.MEMORY_DEFAULTS)
+        self.encoder = encoder if encoder is not None else build_encoder(enc_cfg)
+        self.memory = memory if memory is not None else build_memory(mem_cfg, self.encoder)
+        self.top_k = int(enc_cfg.top_k if top_k is None else top_k)
+        self.metrics = MetricsTracker()              # src/pipeline/vlm_extractor.py:21
+        self.metrics_dir = "metrics"                 # :91 writes metrics/vlm_<run_id>.json relative to the cwd
+        self.last_metrics_path: Optional[str] = None
         self.timings: List[Tuple[str, float]] = []
         self._stager = None
         self._stager_factory = stager_factory  # (frames, H, W, device) -> ingest.FrameStager-like; tests inject a host one
 
     def _read_chunk(self, src, indices) -> List[np.ndarray]:
-        """The reference's per-chunk frame pick (:107-111): unreadable frames are dropped.  Frames taller than 720
-        rows are NOT downscaled on the host: the preprocess kernel's own bilinear resize takes them to the encoder
-        input in one pass (the reference's cv2.resize to 720 rows, :114-116, only shrinks the HTTP payload)."""
+        """The reference's per-chunk frame pick (:107-111): unreadable frames are dropped.  No 720-row downscale
+        (module docstring: the one deliberate deviation)."""
         return [f for f in (src.read(i) for i in indices) if f is not None]
 
     def _stage(self, frames: List[np.ndarray]):
         """Start the H2D copy of a chunk (ingest.FrameStager: pinned slot + copy stream); the stager is sized on the
         first chunk and rebuilt if the frame size changes."""
         h, w = frames[0].shape[:2]
-        cap = max(len(frames), int(self.config.video.frames_per_chunk))
+        cap = max(len(frames), int(cfgmod.section(self.config, "video", cfgmod.VIDEO_DEFAULTS).frames_per_chunk))
         if self._stager is None or self._stager.shape[1:3] != (h, w) or self._stager.shape[0] < len(frames):
             factory = self._stager_factory
             if factory is None:
@@ -115,11 +162,13 @@ class FrameEmbeddingExtractor:
 
     async def process_video(self, video_path: str, output_path: str) -> str:
         run_id = str(uuid.uuid4())
+        logger.info(f"Starting frame-embedding extraction with run ID: {run_id}")
+        video_cfg = cfgmod.section(self.config, "video", cfgmod.VIDEO_DEFAULTS)
         src = open_source(video_path)
         try:
             fps, total_frames = src.fps, src.total
-            total_chunks, plan = chunk_plan(fps, total_frames, self.config.video.chunk_size_seconds,
-                                            self.config.video.frames_per_chunk)
+            total_chunks, plan = chunk_plan(fps, total_frames, video_cfg.chunk_size_seconds,
+                                            video_cfg.frames_per_chunk)
             results = []
 
             def read_and_stage(pi):
@@ -159,13 +208,21 @@ class FrameEmbeddingExtractor:
                     "similar": similar,
                 })
                 self.timings.append((f"chunk_{chunk_idx}", chunk_time))
-            cfg = self.config.dict() if hasattr(self.config, "dict") else None
+                self.metrics.record_timing(f"chunk_{chunk_idx}", "vlm_inference", chunk_time)   # key of :73
             output_data = {
-                "metadata": {"run_id": run_id, "video_path": video_path, "total_chunks": total_chunks, "config": cfg},
+                "metadata": {"run_id": run_id, "video_path": video_path, "total_chunks": total_chunks,
+                             "config": cfgmod.config_dict(self.config)},
                 "results": results,
             }
             with open(output_path, "w") as f:
-                json.dump(output_data, f, indent=2)
+                json.dump(output_data, f, indent=2, default=str)
+            logger.info(f"Frame-embedding extraction completed. Output saved to: {output_path}")
+            import os
+            self.last_metrics_path = os.path.join(self.metrics_dir, f"vlm_{run_id}.json")
+            self.metrics.save_metrics(self.last_metrics_path)
+            mem_cfg = cfgmod.section(self.config, "memory", cfgmod.MEMORY_DEFAULTS)
+            if mem_cfg.snapshot:
+                self.memory.snapshot(mem_cfg.snapshot)
             return output_path
         finally:
             src.release()

@@ -52,7 +52,8 @@ class HipHybridMixin:
 
     _hip: Optional[HipVectorSearch] = None
 
-    def attach_memory(self, memory, min_score: float = 0.3, score_mode: int = _lib.VM_SCORE_RAW, splitter=None):
+    def attach_memory(self, memory, *, score_mode: int, min_score: float = 0.3, splitter=None):
+        """``score_mode`` is required: see similarity.HipVectorSearch (Neo4j's score mapping is unpinned)."""
         self._hip = HipVectorSearch(memory, self.embedder, self.config, min_score=min_score, score_mode=score_mode,
                                     splitter=splitter)
         return self

@@ -45,13 +45,31 @@ def merge_batch_similarities(batch_similarities: Sequence[Sequence[Tuple[str, fl
     return final_score_list[:top_k_similar_batch]
 
 
+def _length(e) -> int:
+    return int(e.shape[-1]) if isinstance(e, torch.Tensor) else len(e)
+
+
 def batch_similarities(memory: EmbeddingMemory, chunk_embeddings: Sequence, top_k: int
                        ) -> List[List[Tuple[str, float]]]:
-    """One batched top-k launch for every non-failed query; result re-threaded into the reference's list shape."""
+    """One batched top-k launch for every non-failed query; result re-threaded into the reference's list shape.
+
+    A query whose length differs from the stored vectors' scores 0.0 against EVERY row in the reference
+    (``_cosine_similarity``: ``if len(vec1) != len(vec2): return 0.0``, src/components/pre_llm_injector.py:378-379), and
+    the stable descending sort (:369) then keeps memory order: the answer is the first ``top_k`` stored chunks, each
+    with score 0.0.  That is reproduced on the host (no arithmetic involved) instead of raising."""
     ok_idx = [i for i, e in enumerate(chunk_embeddings) if not isinstance(e, Exception) and e is not None]
     out: List[List[Tuple[str, float]]] = [[] for _ in chunk_embeddings]
     if not ok_idx or memory.searchable == 0 or top_k <= 0:
         return out
+    wrong = [i for i in ok_idx if _length(chunk_embeddings[i]) != memory.dim]
+    if wrong:
+        first_row = len(memory) - memory.searchable
+        zeros = [(memory.id_of(first_row + j), 0.0) for j in range(min(top_k, memory.searchable))]
+        for i in wrong:
+            out[i] = list(zeros)
+        ok_idx = [i for i in ok_idx if i not in set(wrong)]
+        if not ok_idx:
+            return out
     first = chunk_embeddings[ok_idx[0]]
     if isinstance(first, torch.Tensor):
         q = torch.stack([chunk_embeddings[i] for i in ok_idx])
@@ -86,9 +104,16 @@ class HipPreLLMSimilarity:
 class HipVectorSearch:
     """Mixin / stand-alone object for HybridRetriever's vector leg."""
 
-    def __init__(self, memory: EmbeddingMemory, embedder: Any, config: Any, min_score: float = 0.3,
-                 score_mode: int = _lib.VM_SCORE_RAW,
-                 splitter: Optional[Callable[[str], List[str]]] = None):
+    def __init__(self, memory: EmbeddingMemory, embedder: Any, config: Any, *, score_mode: int,
+                 min_score: float = 0.3, splitter: Optional[Callable[[str], List[str]]] = None):
+        """``score_mode`` is REQUIRED (keyword): the reference filters on Neo4j's
+        ``vector.similarity.cosine(...) > 0.3`` (src/pipeline/retriever_hybrid.py:296-298), a third-party function of an
+        unpinned server image whose value may be the raw cosine or its [0,1] mapping (1+cos)/2 - with the literal 0.3
+        meaning cos > 0.3 in one case and cos > -0.4 in the other.  Nothing in the reference pins it (parity unpinned,
+        SURVEY.md 8 a10), so the integrator states which one their deployment had: ``_lib.VM_SCORE_RAW`` or
+        ``_lib.VM_SCORE_UNIT_INTERVAL``; ``min_score`` (default: the reference's literal) is compared AFTER the mapping."""
+        if score_mode not in (_lib.VM_SCORE_RAW, _lib.VM_SCORE_UNIT_INTERVAL):
+            raise ValueError("score_mode must be VM_SCORE_RAW or VM_SCORE_UNIT_INTERVAL")
         self.memory, self.embedder, self.config = memory, embedder, config
         self.min_score, self.score_mode, self.splitter = min_score, score_mode, splitter
 

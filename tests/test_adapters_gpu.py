@@ -61,6 +61,13 @@ def test_calculate_batch_similarities_matches_reference_loop():
     want = S.calculate_batch_similarities_ref(chunk_embeddings, dict(zip(ids, rows16)), 3)
     assert got == want and got[1] == []                           # ids, fp64 scores, [] for the failed embed
     assert merge_batch_similarities(got, 2) == S.merge_batch_similarities_ref(want, 2)
+    # a query of the wrong length scores 0.0 against every row in the reference (pre_llm_injector.py:378-379); the
+    # stable sort then keeps memory order: first k chunks, score 0.0 - not an exception
+    short = q16[0][:D - 5]
+    mixed = [q16[0], short, q16[1]]
+    got_m = asyncio.run(sim._calculate_batch_similarities(mixed, neo4j_handler=None))
+    want_m = S.calculate_batch_similarities_ref(mixed, dict(zip(ids, rows16)), 3)
+    assert got_m == want_m and got_m[1] == [(ids[0], 0.0), (ids[1], 0.0), (ids[2], 0.0)]
     # an empty memory gives empty lists, not an error (first batch of a run)
     from vidmem.memory import EmbeddingMemory
     empty = HipPreLLMSimilarity(EmbeddingMemory(16, D, "f16"), SimpleNamespace(top_k_chunk_with_batch_similarity=3))
@@ -108,7 +115,9 @@ def test_post_compress_chunks_matches_reference_filter():
     q16 = _f16_lists(q[None])[0]
     table = dict(segs, **{"the query": q16})
     cfg = SimpleNamespace(top_k_chunks=6, compression_threshold=0.6, top_k=4)
-    vs = HipVectorSearch(mem, DictEmbedder(table), cfg, splitter=lambda text: text.split("|"))
+    from vidmem import _lib
+    vs = HipVectorSearch(mem, DictEmbedder(table), cfg, score_mode=_lib.VM_SCORE_RAW,
+                         splitter=lambda text: text.split("|"))
     got = asyncio.run(vs._post_compress_chunks("the query", chunks))
     order = [(c, name) for c in range(4) for name in chunks[c]["content"].split("|") if name in segs]
     want = S.post_compress_ref(q16, [segs[name] for _, name in order], threshold=0.6, top_k=4)
@@ -133,7 +142,10 @@ def test_hybrid_mixin_on_a_retriever_shaped_class():
     class GpuRetriever(fusion.HipHybridMixin, Base):
         pass
 
-    r = GpuRetriever().attach_memory(mem, min_score=0.3)
+    from vidmem import _lib
+    with pytest.raises(TypeError):
+        GpuRetriever().attach_memory(mem)                   # the score mapping is never guessed
+    r = GpuRetriever().attach_memory(mem, score_mode=_lib.VM_SCORE_RAW, min_score=0.3)
     hits = asyncio.run(r._vector_search_chunks(None, "q"))
     assert hits[0]["id"] == ids[10] and abs(hits[0]["score"] - 1.0) < 1e-12
     fused = fusion.fuse_result_chunks(hits, [{"id": "run_9_5"}], r.config.top_k_chunks)

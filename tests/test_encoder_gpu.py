@@ -18,11 +18,32 @@ from oracle import vit_ref as V
 pytestmark = pytest.mark.gpu
 
 TD = {"f16": torch.float16, "bf16": torch.bfloat16}
-# north_star tolerance (1e-3 relative) holds for the fp16 path.  A bf16 value carries 8 significant bits: rounding
-# the OUTPUT alone costs ~1.1e-3 relative L2 (two independently rounded vectors), before any of the ~10 bf16 storage
-# points per layer flips a rounding, so the bf16 path is held to 2 bf16 ulps (2 * 2^-8) instead and says so.
-REL_TOL = {"f16": 1e-3, "bf16": 2 * 2.0 ** -8}   # vs the quant-aware oracle
-FP32_TOL = {"f16": 2e-3, "bf16": 1.6e-2}         # vs the un-quantised oracle: a few ulps of the 16-bit type
+# Bars.  north_star: embeddings within 1e-3 relative of the CPU path.
+#   fp16: 1e-3, against BOTH oracles (same storage points; plain fp32).
+#   bf16: 1e-3 is below what ANY implementation with bf16 matrix operands can reach - tests/golden/bf16_floor.py prices
+#         every 16-bit storage point of CLIP-L/14-336 on the CPU: rounding ONLY the operands of the matrix units costs
+#         4.9e-3 (the weights alone 3.6e-3), the bf16 output alone 1.6e-3.  The bar is therefore 1.5 x that measured
+#         floor (committed table tests/golden/bf16_floor_clip_l14_336_bf16.json; for the short stacks below the floor of
+#         the SAME stack is evaluated in the test), and the device stores everything that is not a matrix operand in
+#         fp16 (csrc/vm_kernels.h EPI_DELTA16).  Against the quant-aware oracle the bar is the same: one flipped bf16
+#         rounding is 2^-8 of an element, so that comparison is as noisy as the fp32 one.
+CONTRACT = 1e-3
+FLOOR_SLACK = 1.5
+_FLOOR_JSON = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bf16_floor_clip_l14_336_bf16.json")
+
+
+def floor_bar_full_clip():
+    import json
+    rows = json.load(open(_FLOOR_JSON))["rows"]
+    return FLOOR_SLACK * rows["FLOOR: matrix operands only -> bf16"]
+
+
+def bar_for(dtype, spec=None, w=None, px=None, want_32=None):
+    """fp16: the contract.  bf16: 1.5 x the operand-only floor of this very stack (oracle, CPU)."""
+    if dtype == "f16":
+        return CONTRACT
+    floor = rel(V.vit_forward_ref(spec, w, px, quant={p: "bf16" for p in V.OPERAND_POINTS}), want_32)
+    return max(CONTRACT, FLOOR_SLACK * floor)
 
 
 def rel(a, b):
@@ -104,8 +125,11 @@ def test_short_stacks_match_oracle(dtype, layers, act, pre_ln, hidden, heads, ml
     got = enc.encode_patches(enc.patches_from_pixels(torch.from_numpy(px))).float().cpu().numpy()
     want_q = V.vit_forward_ref(spec, w, px, quant=dtype)
     want_32 = V.vit_forward_ref(spec, w, px, quant=None)
-    assert rel(got, want_q) < REL_TOL[dtype], rel(got, want_q)
-    assert rel(got, want_32) < FP32_TOL[dtype], rel(got, want_32)
+    bar = bar_for(dtype, spec, w, px, want_32)
+    print(f"{dtype} L={layers} H={hidden}: vs quant-aware {rel(got, want_q):.2e}, vs fp32 {rel(got, want_32):.2e}, "
+          f"bar {bar:.2e}")
+    assert rel(got, want_q) < bar, (rel(got, want_q), bar)
+    assert rel(got, want_32) < bar, (rel(got, want_32), bar)
     assert np.allclose(np.linalg.norm(got, axis=1), 1.0, atol=4e-3)
 
 
@@ -119,7 +143,7 @@ def test_projection_head_and_no_l2():
     got = enc.encode_patches(enc.patches_from_pixels(torch.from_numpy(px)), l2_normalise=False)
     assert got.shape == (2, 128)
     want = V.vit_forward_ref(spec, w, px, quant="f16", l2_normalise=False)
-    assert rel(got.float().cpu().numpy(), want) < REL_TOL["f16"]
+    assert rel(got.float().cpu().numpy(), want) < CONTRACT
 
 
 @pytest.mark.parametrize("name,dtype", [("vit_b16_224", "f16"), ("clip_l14_336", "bf16")])
@@ -132,11 +156,16 @@ def test_full_models_match_golden(name, dtype, golden):
     enc = _encoder(spec, w, dtype)
     got = enc.encode_patches(enc.patches_from_pixels(torch.from_numpy(px))).float().cpu().numpy()
     e_q, e_32 = rel(got, golden[name + "/" + dtype]), rel(got, golden[name + "/fp32"])
-    print(f"{name} {dtype}: rel err vs quant-aware golden {e_q:.2e}, vs fp32 golden {e_32:.2e}")
-    assert e_q < REL_TOL[dtype]
-    assert e_32 < FP32_TOL[dtype]
-    cos = (got * golden[name + "/fp32"]).sum(1)
-    assert (cos > 1 - (5e-5 if dtype == "f16" else 1e-3)).all()  # 16-bit output: |e| is 1 only to ~1 ulp
+    bar = CONTRACT if dtype == "f16" else floor_bar_full_clip()
+    print(f"{name} {dtype}: rel err vs quant-aware golden {e_q:.2e}, vs fp32 golden {e_32:.2e}, bar {bar:.2e}")
+    assert e_q < bar
+    assert e_32 < bar
+    # the same bar per frame and as an angle: for unit vectors 1 - cos = e^2 / 2 (directions compared in fp64; the
+    # 16-bit output's own norm is 1 only to an ulp)
+    g64, f64 = got.astype(np.float64), golden[name + "/fp32"].astype(np.float64)
+    cos = (g64 * f64).sum(1) / (np.linalg.norm(g64, axis=1) * np.linalg.norm(f64, axis=1))
+    assert (1.0 - cos < 0.5 * bar * bar).all(), (1.0 - cos).max()
+    assert all(rel(g64[i], f64[i]) < bar for i in range(g64.shape[0]))
 
 
 def test_batching_is_invisible(monkeypatch):
@@ -179,4 +208,5 @@ def test_bench_size_batches_take_the_big_kernels_and_agree(name, dtype, n):
     assert worst == 0.0
     px = F.preprocess_ref(frames[picks[:3]].cpu().numpy(), S, spec["mean"], spec["std"], layout="chw")
     want = V.vit_forward_ref(spec, w, px, quant=dtype)
-    assert rel(big[:3].float().cpu().numpy(), want) < REL_TOL[dtype]
+    bar = CONTRACT if dtype == "f16" else floor_bar_full_clip()
+    assert rel(big[:3].float().cpu().numpy(), want) < bar

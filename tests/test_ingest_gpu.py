@@ -85,6 +85,15 @@ def test_extractor_pipeline_matches_direct_path(tmp_path):
         first = ref.append(emb)
         assert res["embedding_rows"] == list(range(first, first + len(idx))) and res["time"] == label
     assert torch.equal(ref.rows_tensor(), mem.rows_tensor())
+    # ... and the reported neighbours against the ORACLE over the stored rows (not only against the HIP path itself)
+    from oracle import cref
+    bits = lambda t: t.contiguous().view(torch.int16).cpu().numpy().view(np.uint16)
+    stored = mem.rows_tensor()
+    for res in out["results"][1:]:
+        lo = res["embedding_rows"][0]
+        want_r, want_s = cref.cosine_topk(bits(stored[lo:lo + 6]), bits(stored[:lo]), 3, dtype="f16")
+        assert [[(sc, mem.ids.index(rid)) for rid, sc in q] for q in res["similar"]] == \
+            [[(float(s), int(r)) for r, s in zip(rq, sq)] for rq, sq in zip(want_r, want_s)]
 
 
 def test_streaming_push_host_equals_push_device():

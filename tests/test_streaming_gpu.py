@@ -118,8 +118,9 @@ def test_session_survives_larger_eager_calls_on_the_same_encoder_and_memory():
     mem.append(seed_rows)
     sess = StreamingSession(enc, mem, B, 224, 224, top_k=k, warmup=1)
     f0 = torch.from_numpy(syn.frames_u8(200, B, 224, 224)).cuda()
-    emb0, s0, r0 = [t.clone() for t in sess.push(f0)]
-    torch.cuda.synchronize()
+    res0 = sess.push(f0)
+    torch.cuda.synchronize()                          # the replay runs on the session's stream
+    emb0, s0, r0 = [t.clone() for t in res0]
     big = torch.from_numpy(syn.frames_u8(201, 96, 224, 224)).cuda()
     e_big = enc.embed_frames(big)                     # grows the encoder's shared workspace
     mem.topk(e_big, 40)                               # grows the memory's shared top-k scratch
