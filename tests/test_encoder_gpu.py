@@ -38,11 +38,12 @@ def floor_bar_full_clip():
     return FLOOR_SLACK * rows["FLOOR: matrix operands only -> bf16"]
 
 
-def bar_for(dtype, spec=None, w=None, px=None, want_32=None):
-    """fp16: the contract.  bf16: 1.5 x the operand-only floor of this very stack (oracle, CPU)."""
-    if dtype == "f16":
-        return CONTRACT
-    floor = rel(V.vit_forward_ref(spec, w, px, quant={p: "bf16" for p in V.OPERAND_POINTS}), want_32)
+def bar_for(dtype, spec, w, px, want_32):
+    """The contract, unless 1.5 x the operand-only floor of this very stack (oracle, CPU) is above it: what no
+    implementation with `dtype` matrix operands can beat.  That is every bf16 stack, and the fp16 short stacks with
+    the wide (std 0.05) test weights, whose floor alone is 1.1e-3; the full fp16 models (floor 7.6e-4) are held to the
+    contract itself in test_full_models_match_golden."""
+    floor = rel(V.vit_forward_ref(spec, w, px, quant={p: dtype for p in V.OPERAND_POINTS}), want_32)
     return max(CONTRACT, FLOOR_SLACK * floor)
 
 
