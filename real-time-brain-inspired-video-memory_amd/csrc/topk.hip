@@ -323,7 +323,8 @@ __global__ void __launch_bounds__(FIN_THREADS)
                          const int *__restrict__ part_o, int k, int use_min, double min_score, int score_mode,
                          int64_t row_stride, int64_t row_offset, double *__restrict__ out_scores,
                          int64_t *__restrict__ out_rows, int *__restrict__ uncertified,
-                         int *__restrict__ qflags, float *__restrict__ thr_s_out, int *__restrict__ thr_o_out, int stage_rows) {
+                         int *__restrict__ qflags, float *__restrict__ thr_s_out, int *__restrict__ thr_o_out, int stage_rows,
+                         const int *__restrict__ mark) {
     using E = vm_elem<DT>;
     __shared__ float hs[MAX_BLOCKS];
     __shared__ int ho[MAX_BLOCKS];
@@ -603,7 +604,10 @@ __global__ void __launch_bounds__(FIN_THREADS)
         const int kth = (k < nfin ? k : nfin) - 1;
         if (rank == kth && (uncertified || qflags)) {
             const bool all_rows_are_candidates = rv.n <= (int64_t)nfin;
-            if (!all_rows_are_candidates && qn != 0.0) {
+            if (mark && mark[q]) {  // emit scan: candidate buffer overflowed / unranked ties -> exhaustive redo
+                if (uncertified) atomicAdd(uncertified, 1);
+                if (qflags) qflags[q] = 1;
+            } else if (!all_rows_are_candidates && qn != 0.0) {
                 const float bound_f32 = fs[KL - 1];  // best possible fp32 score of a rejected row (x 1/||q||)
                 const double eps = 2.0 * (double)(D + 8) * 5.9604644775390625e-08;  // 2*(D+8)*2^-24
                 const double reject = (double)bound_f32 / qn + eps;
@@ -649,6 +653,8 @@ __global__ void __launch_bounds__(256)
     }
 }
 
+constexpr int64_t SAMPLE_ROWS = 16384;  // rows of the sampling pre-pass (multi-tile query groups only)
+
 struct ScanCfg {
     int KL, QT;
 };
@@ -668,6 +674,7 @@ struct ScanPlan {
     int q_pad, qgroups, nblk;
     size_t lds;
     size_t part_bytes;
+    bool emit;  // many queries: query-stationary emit scan (topk_emit.hip) instead of the per-lane-list scan
 };
 ScanPlan make_plan(const vm_memory *m, int Q, int k) {
     ScanPlan p;
@@ -695,10 +702,10 @@ ScanPlan make_plan(const vm_memory *m, int Q, int k) {
     const size_t lds_q = (size_t)qpg * m->D * 2, lds_m = (size_t)nw * qpg * p.cfg.KL * 8;
     p.lds = lds_q > lds_m ? lds_q : lds_m;
     p.part_bytes = vm_align_up((size_t)p.nblk * p.q_pad * p.cfg.KL * 4, 256);
+    p.emit = vm_topk_emit_supported(m, Q, p.cfg.KL) && m->cap >= 4 * SAMPLE_ROWS;
     return p;
 }
 
-constexpr int64_t SAMPLE_ROWS = 16384;  // rows of the sampling pre-pass (multi-tile query groups only)
 
 template <int DT, int KL, int QT>
 int launch_scan(vm_memory *m, const ScanPlan &p, int nblk, int64_t row_limit, const float *thr_s, const int *thr_o,
@@ -738,14 +745,19 @@ int run_topk_kl(vm_memory *m, const ScanPlan &p, const void *queries, int Q, int
     int rc;
     const float *use_ts = nullptr;
     const int *use_to = nullptr;
-    // Multi-tile query groups are insert-bound, not HBM-bound: a cheap pre-pass over the first SAMPLE_ROWS slots
-    // gives every query a valid cut (the KL-th best of that subset), and the full scan then skips the sorted insert
-    // for everything below it.
-    if (p.cfg.QT >= 2 && m->cap >= 4 * SAMPLE_ROWS) {  // 100k-row shard, 880 queries: scan 1.06 -> 0.93 ms
+    const int *mark = nullptr;
+    int fin_nblk = p.nblk;
+    // Multi-tile query groups are insert-bound, not HBM-bound: a cheap pre-pass over the first sample rows gives
+    // every query a valid cut (the KL-th best of that subset); the full scan then either skips the sorted insert for
+    // everything below it (list scan) or emits only what is at or above it (emit scan, topk_emit.hip).
+    const bool emit = p.emit;
+    if ((p.cfg.QT >= 2 || emit) && m->cap >= 4 * SAMPLE_ROWS) {  // 100k-row shard, 880 queries: scan 1.06 -> 0.93 ms
         const int nw = SCAN_THREADS / 64;
-        int nblk_pre = (int)((SAMPLE_ROWS / 16 + nw - 1) / nw);
+        // the emit scan's candidate count per query is ~ rows * KL / sample: keep it near 1 k for any memory size
+        const int64_t sample = emit && m->cap / 64 > SAMPLE_ROWS ? (m->cap / 64 + 15) / 16 * 16 : SAMPLE_ROWS;
+        int nblk_pre = (int)((sample / 16 + nw - 1) / nw);
         if (nblk_pre > p.nblk) nblk_pre = p.nblk;
-        if ((rc = launch_scan_qt<DT, KL>(m, p, nblk_pre, SAMPLE_ROWS, nullptr, nullptr, queries, Q, part_s, part_o,
+        if ((rc = launch_scan_qt<DT, KL>(m, p, nblk_pre, sample, nullptr, nullptr, queries, Q, part_s, part_o,
                                          st)) != VM_OK)
             return rc;
         {
@@ -753,14 +765,26 @@ int run_topk_kl(vm_memory *m, const ScanPlan &p, const void *queries, int Q, int
             topk_finalize_kernel<DT, KL, true><<<Q, FIN_THREADS, (size_t)m->D * 2, st>>>(
                 m->rows, m->norm64, (const uint16_t *)queries, m->d_total, m->cap, m->ring, m->D, p.q_pad, nblk_pre,
                 part_s, part_o, k, use_min, min_score, score_mode, row_stride, row_offset, out_scores, out_rows,
-                nullptr, nullptr, thr_s, thr_o, 0);
+                nullptr, nullptr, thr_s, thr_o, 0, nullptr);
             VM_LAUNCH_CHECK(m->ctx);
         }
         use_ts = thr_s;
         use_to = thr_o;
     }
-    if ((rc = launch_scan_qt<DT, KL>(m, p, p.nblk, INT64_MAX, use_ts, use_to, queries, Q, part_s, part_o, st)) !=
-        VM_OK)
+    if (emit) {
+        int *cand_cnt = (int *)((char *)thr_s + vm_align_up((size_t)p.q_pad * 8, 256));
+        int *mk = (int *)((char *)cand_cnt + vm_align_up((size_t)p.q_pad * 4, 256));
+        float *cand_s = (float *)((char *)mk + vm_align_up((size_t)p.q_pad * 4, 256));
+        int *cand_o = (int *)((char *)cand_s + vm_align_up((size_t)p.q_pad * VM_EMIT_CAP * 4, 256));
+        hipError_t e = hipMemsetAsync(cand_cnt, 0, vm_align_up((size_t)p.q_pad * 4, 256), st);
+        if (e != hipSuccess) return vm_fail(m->ctx, VM_ERR_HIP, "memset: %s", hipGetErrorString(e));
+        if ((rc = vm_topk_emit_scan(m, queries, Q, use_ts, use_to, cand_cnt, cand_s, cand_o, st)) != VM_OK) return rc;
+        if ((rc = vm_topk_emit_compact(m, Q, KL, p.q_pad, cand_cnt, cand_s, cand_o, part_s, part_o, mk, st)) != VM_OK)
+            return rc;
+        mark = mk;
+        fin_nblk = 1;
+    } else if ((rc = launch_scan_qt<DT, KL>(m, p, p.nblk, INT64_MAX, use_ts, use_to, queries, Q, part_s, part_o,
+                                            st)) != VM_OK)
         return rc;
     vm_prof_scope prof(m->ctx, VM_PROF_TOPK_FINALIZE, st);
     size_t fin_lds = (size_t)m->D * 2;
@@ -779,9 +803,9 @@ int run_topk_kl(vm_memory *m, const ScanPlan &p, const void *queries, int Q, int
         }
     }
     topk_finalize_kernel<DT, KL, false><<<Q, FIN_THREADS, fin_lds, st>>>(
-        m->rows, m->norm64, (const uint16_t *)queries, m->d_total, m->cap, m->ring, m->D, p.q_pad, p.nblk, part_s,
+        m->rows, m->norm64, (const uint16_t *)queries, m->d_total, m->cap, m->ring, m->D, p.q_pad, fin_nblk, part_s,
         part_o, k, use_min, min_score, score_mode, row_stride, row_offset, out_scores, out_rows, uncertified, qflags,
-        nullptr, nullptr, stage_rows);
+        nullptr, nullptr, stage_rows, mark);
     VM_LAUNCH_CHECK(m->ctx);
     return VM_OK;
 }
@@ -807,7 +831,8 @@ int run_topk(vm_memory *m, const ScanPlan &p, const void *queries, int Q, int k,
 extern "C" size_t vm_topk_workspace_bytes(const vm_memory *m, int Q, int k) {
     if (!m || Q <= 0 || k <= 0 || k > 58) return 0;
     const ScanPlan p = make_plan(m, Q, k);
-    return 2 * p.part_bytes + vm_align_up((size_t)p.q_pad * 8, 256) + 256;
+    return 2 * p.part_bytes + vm_align_up((size_t)p.q_pad * 8, 256) + (p.emit ? vm_topk_emit_workspace_bytes(p.q_pad) : 0) +
+           256;
 }
 
 extern "C" int vm_topk_cosine(vm_memory *m, const void *queries, int Q, int k, int use_min_score,
@@ -823,7 +848,8 @@ extern "C" int vm_topk_cosine(vm_memory *m, const void *queries, int Q, int k, i
     if (score_mode != VM_SCORE_RAW && score_mode != VM_SCORE_UNIT_INTERVAL)
         return vm_fail(ctx, VM_ERR_INVALID, "bad score_mode %d", score_mode);
     const ScanPlan p = make_plan(m, Q, k);
-    const size_t need = 2 * p.part_bytes + vm_align_up((size_t)p.q_pad * 8, 256);
+    const size_t need = 2 * p.part_bytes + vm_align_up((size_t)p.q_pad * 8, 256) +
+                        (p.emit ? vm_topk_emit_workspace_bytes(p.q_pad) : 0);
     if (!workspace || workspace_bytes < need)
         return vm_fail(ctx, VM_ERR_NOMEM, "vm_topk_cosine: workspace %zu < %zu", workspace_bytes, need);
     if (((uintptr_t)workspace & 15) || ((uintptr_t)queries & 15))

@@ -259,3 +259,59 @@ def test_many_query_groups_bit_exact():
     assert np.array_equal(r.cpu().numpy(), want_r)
     assert np.array_equal(s.cpu().numpy(), want_s)
     assert r[199, :2].tolist() == [12, 65_000]
+
+
+@pytest.mark.parametrize("dtype,D,M,Q,k", [("f16", 768, 100_000, 130, 10), ("bf16", 1024, 70_000, 64, 20),
+                                            ("f16", 256, 300_000, 256, 10), ("f16", 512, 66_000, 49, 5)])
+def test_emit_scan_many_queries_bit_exact(dtype, D, M, Q, k):
+    """Q >= 49 on a memory >= 65536 rows takes the query-stationary EMIT scan (csrc/topk_emit.hip): sample cut,
+    LDS-staged row tiles, threshold emission, compact, exact re-scoring.  Rows and fp64 scores against the C oracle,
+    with planted near-duplicates (top of the list), exact duplicates far apart, a zero query and a zero row, on a
+    RING that has wrapped (device-side head / order mapping inside the emit kernel)."""
+    rng = np.random.default_rng(D + Q)
+    extra = 4_000
+    hist = torch.tensor(rng.standard_normal((M + extra, D)), dtype=torch.float32).to(TD[dtype])
+    q = torch.tensor(rng.standard_normal((Q, D)), dtype=torch.float32).to(TD[dtype])
+    live_lo = extra
+    picks = rng.integers(live_lo, M + extra, 20)
+    q[:20] = (0.7 * hist[picks].float() + 0.3 * q[:20].float()).to(TD[dtype])
+    hist[live_lo + 50_000] = hist[live_lo + 12]         # exact duplicate far apart: lower row id first
+    q[21] = hist[live_lo + 12]
+    q[22] = 0
+    hist[live_lo + 777] = 0
+    mem = _mem(dtype, M, D, ring=True)
+    for lo in range(0, M + extra, 26_000):
+        mem.append(hist[lo:lo + 26_000])
+    mem.reset_uncertified()
+    s, r = mem.topk(q, k)
+    want_r, want_s = cref.cosine_topk(_bits(q), _bits(hist[live_lo:]), k, dtype=dtype)
+    want_r = np.where(want_r >= 0, want_r + live_lo, -1)
+    assert np.array_equal(r.cpu().numpy(), want_r)
+    assert np.array_equal(s.cpu().numpy(), want_s)
+    assert r[21, :2].tolist() == [live_lo + 12, live_lo + 50_000]
+    assert mem.uncertified_count <= 1                   # the zero query ties with everything: it may be redone
+
+
+def test_emit_scan_overflow_and_tie_floods_fall_back_to_the_exhaustive_redo():
+    """More candidates at or above the cut than the per-query buffer holds (5000 copies of the query > 4096 slots), and
+    more exact ties at the KL-th place than the compact kernel ranks (300 copies of another row): the queries must
+    be MARKED, redone exhaustively on the device, and still equal the oracle bit for bit; the other queries of the
+    batch stay on the fast path."""
+    rng = np.random.default_rng(99)
+    D, M, Q, k = 256, 70_000, 64, 10
+    m = torch.tensor(rng.standard_normal((M, D)), dtype=torch.float32).to(torch.float16)
+    q = torch.tensor(rng.standard_normal((Q, D)), dtype=torch.float32).to(torch.float16)
+    flood = rng.choice(np.arange(20_000, M), 5000, replace=False)
+    m[flood] = q[7]
+    ties = rng.choice(np.setdiff1d(np.arange(20_000, M), flood), 300, replace=False)
+    m[ties] = m[19_999]
+    q[9] = m[19_999]
+    mem = _mem("f16", M, D)
+    mem.append(m)
+    mem.reset_uncertified()
+    s, r = mem.topk(q, k)
+    want_r, want_s = cref.cosine_topk(_bits(q), _bits(m), k, dtype="f16")
+    assert np.array_equal(r.cpu().numpy(), want_r)
+    assert np.array_equal(s.cpu().numpy(), want_s)
+    assert r[7].tolist() == sorted(flood.tolist())[:k]
+    assert 2 <= mem.uncertified_count <= 4
