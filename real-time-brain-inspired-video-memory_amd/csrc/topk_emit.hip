@@ -21,6 +21,8 @@
 #include "vm_internal.h"
 
 #include <climits>
+#include <type_traits>
+#include <utility>
 
 namespace {
 
@@ -43,6 +45,21 @@ __device__ __forceinline__ bool better(float s1, int o1, float s2, int o2) {
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// LDS accesses of the hot loop are inline asm: hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front of every LDS
+// access it can see while an LDS-DMA is in flight (an LDS-DMA is a pending LDS write to its alias analysis), which
+// drained the three-tile prefetch once per tile (3 us per tile instead of 1).  The hand-placed counted waits below
+// order every read behind the DMA that feeds it: vmcnt before the tile's barrier, lgkmcnt before each MFMA batch.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));  // a native vector: asm operands must be register values
+template <int OFF>
+__device__ __forceinline__ void lds_read_b128(u32x4 &dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+// wait for the batch (a, b, c, d): the statement names what it guards, so no consumer is scheduled above it
+#define VM_WAIT_LGKM4(N, a, b, c, d) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+__device__ __forceinline__ void lds_write_b32(unsigned addr, unsigned v) {
+    asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
 
 // KS = D / 128.  STAGES tiles of [32 rows][D] 16-bit + 32 reciprocal norms each, then the emission buffers.
@@ -97,6 +114,11 @@ __global__ void __launch_bounds__(EM_THREADS, 1)
     }
     const float ts = have_q ? thr_s[myq] : INFINITY;         // nothing is "at or above" +inf: padded lanes never emit
     const int to = have_q ? thr_o[myq] : -1;
+    // retire these ordinary loads HERE: left pending, hipcc waits for them with vmcnt(0) at their first use inside the
+    // tile loop - in every iteration, which also drains the LDS-DMA prefetch
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) asm volatile("" ::"v"(bq[s]));
+    asm volatile("" ::"v"(ts), "v"(to));
 
     const RingView rv = ring_view(*d_total, cap, ring);
     const int64_t ntiles = (rv.n + EM_ROWS - 1) / EM_ROWS;
@@ -125,14 +147,17 @@ __global__ void __launch_bounds__(EM_THREADS, 1)
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(rnorm + ri), (lds_ptr_t)(dst + TILE_BYTES), 4, 0, 0);
         }
     };
-    constexpr int MY_DMA = PPW + 1;  // upper bound of the LDS-DMA instructions a wave issues per tile
+    static_assert(PIECES % EM_WAVES == 0, "every wave issues exactly PPW row pieces per tile (the counted waits rely on it)");
 
     // emission buffer of this wave
     float *eb_s = reinterpret_cast<float *>(ebuf + wave * EM_WBUF * 12);
     int *eb_o = reinterpret_cast<int *>(eb_s + EM_WBUF);
     int *eb_q = eb_o + EM_WBUF;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;          // LDS byte address of the stages
+    const unsigned eb0 = (unsigned)(uintptr_t)(lds_ptr_t)eb_s;           // ... and of this wave's emission buffer
     int pending = 0;  // wave-uniform
     auto flush = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the asm ds_writes above have landed
         for (int i = lane; i < pending; i += 64) {
             const int q = eb_q[i];
             const int slot = atomicAdd(&cand_cnt[q], 1);
@@ -149,32 +174,71 @@ __global__ void __launch_bounds__(EM_THREADS, 1)
     for (int s = 0; s < STAGES - 1; ++s)
         if (s < my_tiles) stage_tile(bx + (int64_t)s * nbx, s);
 
-    const int sw = r16;  // row & 15 of this lane's A rows (row = 16 rb + r16)
     for (int64_t it = 0; it < my_tiles; ++it) {
         const int64_t tile = bx + it * nbx;
         const int buf = (int)(it % STAGES);
         // retire this tile's DMA: younger ones are those of the (STAGES - 2) tiles staged after it
-        if (it + STAGES - 2 < my_tiles) {
-            if (STAGES == 3) wait_vmcnt<MY_DMA>(); else wait_vmcnt<0>();
+        if (STAGES == 3 && it + 1 < my_tiles) {
+            // exactly the next tile's pieces may stay in flight: PPW per wave, + the norm piece on the last wave
+            if (wave == EM_WAVES - 1) wait_vmcnt<PPW + 1>(); else wait_vmcnt<PPW>();
         } else {
             wait_vmcnt<0>();
         }
         __builtin_amdgcn_s_barrier();  // every wave's pieces of this tile have landed; everyone is done with tile it-1
         if (it + STAGES - 1 < my_tiles) stage_tile(tile + (int64_t)(STAGES - 1) * nbx, (int)((it + STAGES - 1) % STAGES));
         if (!active) continue;
-        const char *tb = stage0 + buf * STAGE_BYTES;
+        const unsigned tb = lds0 + buf * STAGE_BYTES;  // LDS byte address of this tile's image
         for (int rb = rb0; rb < rb1; ++rb) {
-            const char *rowp = tb + (16 * rb + r16) * ROW_BYTES;
-            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            // A fragment of k-step s = 4 m + t: logical chunk c = 16 m + 4 t + h of row (16 rb + r16), stored at chunk
+            // 16 m + ((4 t + h) ^ r16): four per-lane bases (t = 0..3), the m-th 256-byte group is an immediate offset
+            const unsigned rowa = tb + (16 * rb + r16) * ROW_BYTES;
+            unsigned base[4];
 #pragma unroll
-            for (int s = 0; s < KSTEPS; ++s) {
-                const int c = 4 * s + h;
-                const uint4 a = *reinterpret_cast<const uint4 *>(rowp + (((c & ~15) | ((c ^ sw) & 15)) << 4));
-                acc = E::mfma16(__builtin_bit_cast(vec8, a), bq[s], acc);
-            }
-            // acc[j] = <row tile*32 + 16 rb + 4 h + j , query myq>
-            const float4 rn = *reinterpret_cast<const float4 *>(tb + TILE_BYTES + (16 * rb + 4 * h) * 4);
-            const float rnv[4] = {rn.x, rn.y, rn.z, rn.w};
+            for (int t = 0; t < 4; ++t) base[t] = rowa + (((4 * t + h) ^ r16) << 4);
+            u32x4 rn4;
+            lds_read_b128<0>(rn4, tb + TILE_BYTES + (16 * rb + 4 * h) * 4);
+            u32x4 e0, e1, e2, e3, o0, o1, o2, o3;  // even / odd batch of four A fragments
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#define VM_ISSUE4(M, a, b, c, d)                 \
+    lds_read_b128<256 * (M)>(a, base[0]);        \
+    lds_read_b128<256 * (M)>(b, base[1]);        \
+    lds_read_b128<256 * (M)>(c, base[2]);        \
+    lds_read_b128<256 * (M)>(d, base[3]);
+#define VM_MMA4(M, a, b, c, d)                                                  \
+    acc = E::mfma16(__builtin_bit_cast(vec8, a), bq[4 * (M) + 0], acc);        \
+    acc = E::mfma16(__builtin_bit_cast(vec8, b), bq[4 * (M) + 1], acc);        \
+    acc = E::mfma16(__builtin_bit_cast(vec8, c), bq[4 * (M) + 2], acc);        \
+    acc = E::mfma16(__builtin_bit_cast(vec8, d), bq[4 * (M) + 3], acc);
+            // batch m + 1 is issued before batch m is waited for (counted lgkmcnt(4)): one batch always in flight
+#define VM_STEP(M, ca, cb, cc, cd, na, nb, nc, nd)                       \
+    if constexpr ((M) < KS) {                                             \
+        if constexpr ((M) + 1 < KS) {                                     \
+            VM_ISSUE4((M) + 1, na, nb, nc, nd)                            \
+            VM_WAIT_LGKM4(4, ca, cb, cc, cd);                             \
+        } else {                                                          \
+            VM_WAIT_LGKM4(0, ca, cb, cc, cd);                             \
+        }                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                \
+        VM_MMA4(M, ca, cb, cc, cd)                                        \
+    }
+            VM_ISSUE4(0, e0, e1, e2, e3)
+            VM_STEP(0, e0, e1, e2, e3, o0, o1, o2, o3)
+            VM_STEP(1, o0, o1, o2, o3, e0, e1, e2, e3)
+            VM_STEP(2, e0, e1, e2, e3, o0, o1, o2, o3)
+            VM_STEP(3, o0, o1, o2, o3, e0, e1, e2, e3)
+            VM_STEP(4, e0, e1, e2, e3, o0, o1, o2, o3)
+            VM_STEP(5, o0, o1, o2, o3, e0, e1, e2, e3)
+            VM_STEP(6, e0, e1, e2, e3, o0, o1, o2, o3)
+            VM_STEP(7, o0, o1, o2, o3, e0, e1, e2, e3)
+#undef VM_STEP
+#undef VM_MMA4
+#undef VM_ISSUE4
+            // acc[j] = <row tile*32 + 16 rb + 4 h + j , query myq>; rn4 landed before the first batch (in-order queue)
+            // (elements copied out first: __builtin_bit_cast on an ext-vector ELEMENT expression reads element 0 for
+            // every element with this hipcc - all four rows were scaled by rn4.x)
+            const unsigned rn0 = rn4[0], rn1 = rn4[1], rn2 = rn4[2], rn3 = rn4[3];
+            const float rnv[4] = {__builtin_bit_cast(float, rn0), __builtin_bit_cast(float, rn1),
+                                  __builtin_bit_cast(float, rn2), __builtin_bit_cast(float, rn3)};
             const int64_t p0 = tile * EM_ROWS + 16 * rb + 4 * h;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -190,9 +254,9 @@ __global__ void __launch_bounds__(EM_THREADS, 1)
                     if (pass) {
                         const int idx = pending + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
                                                                             __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-                        eb_s[idx] = sc;
-                        eb_o[idx] = o;
-                        eb_q[idx] = myq;
+                        lds_write_b32(eb0 + idx * 4, __builtin_bit_cast(unsigned, sc));
+                        lds_write_b32(eb0 + (EM_WBUF + idx) * 4, (unsigned)o);
+                        lds_write_b32(eb0 + (2 * EM_WBUF + idx) * 4, (unsigned)myq);
                     }
                     pending += __popcll(m);
                 }
