@@ -751,41 +751,55 @@ int run_topk_kl(vm_memory *m, const ScanPlan &p, const void *queries, int Q, int
     // every query a valid cut (the KL-th best of that subset); the full scan then either skips the sorted insert for
     // everything below it (list scan) or emits only what is at or above it (emit scan, topk_emit.hip).
     const bool emit = p.emit;
-    if ((p.cfg.QT >= 2 || emit) && m->cap >= 4 * SAMPLE_ROWS) {  // 100k-row shard, 880 queries: scan 1.06 -> 0.93 ms
-        const int nw = SCAN_THREADS / 64;
-        // the emit scan's candidate count per query is ~ rows * KL / sample: keep it near 1 k for any memory size
-        const int64_t sample = emit && m->cap / 64 > SAMPLE_ROWS ? (m->cap / 64 + 15) / 16 * 16 : SAMPLE_ROWS;
-        int nblk_pre = (int)((sample / 16 + nw - 1) / nw);
-        if (nblk_pre > p.nblk) nblk_pre = p.nblk;
-        if ((rc = launch_scan_qt<DT, KL>(m, p, nblk_pre, sample, nullptr, nullptr, queries, Q, part_s, part_o,
-                                         st)) != VM_OK)
-            return rc;
-        {
-            vm_prof_scope prof(m->ctx, VM_PROF_TOPK_FINALIZE, st);
-            topk_finalize_kernel<DT, KL, true><<<Q, FIN_THREADS, (size_t)m->D * 2, st>>>(
-                m->rows, m->norm64, (const uint16_t *)queries, m->d_total, m->cap, m->ring, m->D, p.q_pad, nblk_pre,
-                part_s, part_o, k, use_min, min_score, score_mode, row_stride, row_offset, out_scores, out_rows,
-                nullptr, nullptr, thr_s, thr_o, 0, nullptr);
-            VM_LAUNCH_CHECK(m->ctx);
-        }
-        use_ts = thr_s;
-        use_to = thr_o;
-    }
     if (emit) {
+        // Cut cascade, all on the emit kernel (topk_emit.hip): (A) the first s0 rows with no cut -> their KL-th best;
+        // (B) the sample rows against that cut -> the KL-th best of the sample (~16 KL candidates per query);
+        // (C) every row against the sample's cut (~rows * KL / sample candidates, kept near 1 k for any memory size).
+        // Each cut is the KL-th best of a SUBSET of the rows, so at least KL rows are at or above it.
         int *cand_cnt = (int *)((char *)thr_s + vm_align_up((size_t)p.q_pad * 8, 256));
         int *mk = (int *)((char *)cand_cnt + vm_align_up((size_t)p.q_pad * 4, 256));
         float *cand_s = (float *)((char *)mk + vm_align_up((size_t)p.q_pad * 4, 256));
         int *cand_o = (int *)((char *)cand_s + vm_align_up((size_t)p.q_pad * VM_EMIT_CAP * 4, 256));
-        hipError_t e = hipMemsetAsync(cand_cnt, 0, vm_align_up((size_t)p.q_pad * 4, 256), st);
-        if (e != hipSuccess) return vm_fail(m->ctx, VM_ERR_HIP, "memset: %s", hipGetErrorString(e));
-        if ((rc = vm_topk_emit_scan(m, queries, Q, use_ts, use_to, cand_cnt, cand_s, cand_o, st)) != VM_OK) return rc;
-        if ((rc = vm_topk_emit_compact(m, Q, KL, p.q_pad, cand_cnt, cand_s, cand_o, part_s, part_o, mk, st)) != VM_OK)
-            return rc;
+        const int64_t sample = m->cap / 64 > SAMPLE_ROWS ? (m->cap / 64 + 31) / 32 * 32 : SAMPLE_ROWS;
+        // pass A keeps EVERY score of the physically first s0 rows (slot = physical row index, dense)
+        const int64_t s0 = VM_EMIT_CAP;
+        const int64_t limits[3] = {s0, sample, INT64_MAX};
+        for (int pass = 0; pass < 3; ++pass) {
+            hipError_t e = hipMemsetAsync(cand_cnt, 0, vm_align_up((size_t)p.q_pad * 4, 256), st);
+            if (e != hipSuccess) return vm_fail(m->ctx, VM_ERR_HIP, "memset: %s", hipGetErrorString(e));
+            if ((rc = vm_topk_emit_scan(m, queries, Q, pass ? thr_s : nullptr, pass ? thr_o : nullptr, cand_cnt, cand_s,
+                                        cand_o, limits[pass], st)) != VM_OK)
+                return rc;
+            const bool last = pass == 2;
+            if ((rc = vm_topk_emit_compact(m, Q, KL, cand_cnt, cand_s, cand_o, part_s, part_o, last ? mk : nullptr,
+                                           last ? nullptr : thr_s, last ? nullptr : thr_o, st)) != VM_OK)
+                return rc;
+        }
         mark = mk;
         fin_nblk = 1;
-    } else if ((rc = launch_scan_qt<DT, KL>(m, p, p.nblk, INT64_MAX, use_ts, use_to, queries, Q, part_s, part_o,
-                                            st)) != VM_OK)
-        return rc;
+    } else {
+        if (p.cfg.QT >= 2 && m->cap >= 4 * SAMPLE_ROWS) {  // 100k-row shard, 880 queries: scan 1.06 -> 0.93 ms
+            const int nw = SCAN_THREADS / 64;
+            int nblk_pre = (int)((SAMPLE_ROWS / 16 + nw - 1) / nw);
+            if (nblk_pre > p.nblk) nblk_pre = p.nblk;
+            if ((rc = launch_scan_qt<DT, KL>(m, p, nblk_pre, SAMPLE_ROWS, nullptr, nullptr, queries, Q, part_s, part_o,
+                                             st)) != VM_OK)
+                return rc;
+            {
+                vm_prof_scope prof(m->ctx, VM_PROF_TOPK_FINALIZE, st);
+                topk_finalize_kernel<DT, KL, true><<<Q, FIN_THREADS, (size_t)m->D * 2, st>>>(
+                    m->rows, m->norm64, (const uint16_t *)queries, m->d_total, m->cap, m->ring, m->D, p.q_pad, nblk_pre,
+                    part_s, part_o, k, use_min, min_score, score_mode, row_stride, row_offset, out_scores, out_rows,
+                    nullptr, nullptr, thr_s, thr_o, 0, nullptr);
+                VM_LAUNCH_CHECK(m->ctx);
+            }
+            use_ts = thr_s;
+            use_to = thr_o;
+        }
+        if ((rc = launch_scan_qt<DT, KL>(m, p, p.nblk, INT64_MAX, use_ts, use_to, queries, Q, part_s, part_o, st)) !=
+            VM_OK)
+            return rc;
+    }
     vm_prof_scope prof(m->ctx, VM_PROF_TOPK_FINALIZE, st);
     size_t fin_lds = (size_t)m->D * 2;
     int stage_rows = 0;

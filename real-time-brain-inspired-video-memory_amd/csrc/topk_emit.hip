@@ -16,8 +16,8 @@
 //     with one atomic per entry, so the hot loop contains no returning global atomic;
 //   * topk_compact_kernel turns each query's candidate buffer into one sorted list of the KL best (bitwise radix
 //     select + rank count of the survivors), which topk.hip's finalize kernel re-scores exactly and certifies as
-//     before.  A query with more candidates than the buffer holds, or more ties at the KL-th place than the kernel
-//     ranks, is marked and goes through the exhaustive redo (topk_exact.hip): never a wrong answer, only a slower one.
+//     before.  A query with more candidates than the buffer holds is marked and goes through the exhaustive redo
+//     (topk_exact.hip): never a wrong answer, only a slower one.
 #include "vm_internal.h"
 
 #include <climits>
@@ -33,7 +33,6 @@ constexpr int EM_QPB = 128;        // queries per superblock (16 per wave)
 constexpr int EM_WBUF = 128;       // entries of a wave's LDS emission buffer (flushed when more than 64 are pending)
 constexpr int CP_THREADS = 256;
 constexpr int CP_PER_THREAD = VM_EMIT_CAP / CP_THREADS;
-constexpr int CP_SURV = 256;       // survivors the compact kernel ranks
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *gbl_ptr_t;
@@ -63,12 +62,15 @@ __device__ __forceinline__ void lds_write_b32(unsigned addr, unsigned v) {
 }
 
 // KS = D / 128.  STAGES tiles of [32 rows][D] 16-bit + 32 reciprocal norms each, then the emission buffers.
-template <int DT, int KS>
+// NG = 16-query groups per wave: 1 (<= 128 queries per superblock: HBM-bound) or 2 (<= 256: every A fragment read from
+// LDS feeds two MFMAs; with one group per wave the eight waves' A reads - 384 KB per tile - saturate the LDS).
+// thr_s == null: no cut, every score is emitted (the first pass of the cut cascade, over a few hundred rows).
+template <int DT, int KS, int NG>
 __global__ void __launch_bounds__(EM_THREADS, 1)
     topk_emit_kernel(const uint16_t *__restrict__ mem, const float *__restrict__ rnorm,
                      const uint16_t *__restrict__ queries, const int64_t *__restrict__ d_total, int64_t cap, int ring,
                      int Q, const float *__restrict__ thr_s, const int *__restrict__ thr_o, int *__restrict__ cand_cnt,
-                     float *__restrict__ cand_s, int *__restrict__ cand_o, int nsuper) {
+                     float *__restrict__ cand_s, int *__restrict__ cand_o, int nsuper, int64_t row_limit) {
     using E = vm_elem<DT>;
     using vec8 = typename E::vec8;
     constexpr int D = 128 * KS;
@@ -79,6 +81,9 @@ __global__ void __launch_bounds__(EM_THREADS, 1)
     constexpr int PIECES = TILE_BYTES / 1024;                // 1 KiB LDS-DMA pieces per tile
     constexpr int PPW = (PIECES + EM_WAVES - 1) / EM_WAVES;  // pieces a wave issues per tile (+1 norm piece: wave 0)
     constexpr int KSTEPS = D / 32;
+    // two batches of four A fragments in flight per wave where the registers allow it; NG = 2 (2 x 16 KS registers of
+    // queries) and D = 1024 run one batch at a time and rely on the partner wave to cover the LDS round trip
+    constexpr bool DBUF = NG == 1 && KS <= 6;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *stage0 = smem;
     char *ebuf = smem + STAGES * STAGE_BYTES;                // [waves][EM_WBUF] {f32 score, i32 order, i32 query}
@@ -93,59 +98,71 @@ __global__ void __launch_bounds__(EM_THREADS, 1)
     if ((total_wg & 7) == 0) v = (blockIdx.x & 7) * (total_wg >> 3) + (blockIdx.x >> 3);
     const int nbx = total_wg / nsuper;
     const int bx = v / nsuper, by = v - bx * nsuper;
-    const int q0 = by * EM_QPB;
-    const int nq = Q - q0 < EM_QPB ? Q - q0 : EM_QPB;       // queries of this superblock
-    const int G = (nq + 15) >> 4;                            // 16-query groups in use (1..8)
-    // G <= 4: two waves per group, one 16-row block of every tile each; G > 4: one wave per group, both row blocks
-    const bool paired = G <= 4;
-    const int g = paired ? (wave >> 1) : wave;
+    constexpr int QPB = EM_QPB * NG;
+    const int q0 = by * QPB;
+    const int nq = Q - q0 < QPB ? Q - q0 : QPB;              // queries of this superblock
+    const int G = (nq + 15) >> 4;                            // 16-query groups in use (1 .. 8 NG)
+    // NG = 1, G <= 4: two waves per group, one 16-row block of every tile each; otherwise a wave takes both row blocks
+    // of a tile for its NG groups
+    const bool paired = NG == 1 && G <= 4;
+    const int g = paired ? (wave >> 1) : wave * NG;          // first group of this wave
     const int rb0 = paired ? (wave & 1) : 0, rb1 = paired ? (wave & 1) + 1 : 2;
     const bool active = g < G;
-    const int myq = q0 + 16 * g + r16;                       // this lane's query
-    const bool have_q = active && myq < Q;
 
-    // the wave's 16 queries as B fragments: lane (r16, h) holds query r16, elements 32 s + 8 h .. + 7 of every k-step
-    vec8 bq[KSTEPS];
+    // the wave's queries as B fragments: lane (r16, h) holds query r16 of a group, elements 32 s + 8 h .. + 7 of every
+    // k-step; the cut of that query; padded lanes get +inf (nothing is "at or above" it: they never emit)
+    vec8 bq[NG][KSTEPS];
+    int myq[NG];
+    float ts[NG];
+    int to[NG];
 #pragma unroll
-    for (int s = 0; s < KSTEPS; ++s) {
-        uint4 u = make_uint4(0, 0, 0, 0);
-        if (have_q) u = *reinterpret_cast<const uint4 *>(queries + (size_t)myq * D + 32 * s + 8 * h);
-        bq[s] = __builtin_bit_cast(vec8, u);
+    for (int u = 0; u < NG; ++u) {
+        myq[u] = q0 + 16 * (g + u) + r16;
+        const bool have_q = active && g + u < G && myq[u] < Q;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            uint4 w = make_uint4(0, 0, 0, 0);
+            if (have_q) w = *reinterpret_cast<const uint4 *>(queries + (size_t)myq[u] * D + 32 * s + 8 * h);
+            bq[u][s] = __builtin_bit_cast(vec8, w);
+        }
+        ts[u] = have_q ? (thr_s ? thr_s[myq[u]] : -INFINITY) : INFINITY;
+        to[u] = have_q ? (thr_s ? thr_o[myq[u]] : INT_MAX) : -1;
     }
-    const float ts = have_q ? thr_s[myq] : INFINITY;         // nothing is "at or above" +inf: padded lanes never emit
-    const int to = have_q ? thr_o[myq] : -1;
     // retire these ordinary loads HERE: left pending, hipcc waits for them with vmcnt(0) at their first use inside the
     // tile loop - in every iteration, which also drains the LDS-DMA prefetch
 #pragma unroll
-    for (int s = 0; s < KSTEPS; ++s) asm volatile("" ::"v"(bq[s]));
-    asm volatile("" ::"v"(ts), "v"(to));
+    for (int u = 0; u < NG; ++u) {
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) asm volatile("" ::"v"(bq[u][s]));
+        asm volatile("" ::"v"(ts[u]), "v"(to[u]));
+    }
 
-    const RingView rv = ring_view(*d_total, cap, ring);
+    RingView rv = ring_view(*d_total, cap, ring);
+    if (rv.n > row_limit) rv.n = row_limit;  // cut cascade: the sample passes scan only the first row_limit slots
     const int64_t ntiles = (rv.n + EM_ROWS - 1) / EM_ROWS;
     const int64_t my_tiles = bx < ntiles ? (ntiles - bx + nbx - 1) / nbx : 0;   // tiles bx, bx + nbx, ...
 
     // LDS-DMA of one tile: piece p covers LDS bytes [1024 p, 1024 p + 1024) of the stage; lane -> (row, chunk') of the
     // linear image; the source chunk is chunk' ^ (row & 15) (swizzle on the source address, the reads apply it again)
+    auto stage_piece = [&](int64_t tile, int buf, int i) {   // i-th of this wave's PPW row pieces of a tile
+        const int p = wave * PPW + i;
+        const int off = p * 1024 + lane * 16;
+        const int row = off / ROW_BYTES, cp = (off - row * ROW_BYTES) >> 4;
+        const int c = cp ^ (row & 15);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(mem + ((size_t)tile * EM_ROWS + row) * D + c * 8),
+                                         (lds_ptr_t)(stage0 + buf * STAGE_BYTES + p * 1024), 16, 0, 0);
+    };
+    auto stage_norm = [&](int64_t tile, int buf) {  // last wave only: 64 reciprocal norms (this tile's 32 + 32 more)
+        int64_t ri = tile * EM_ROWS + lane;
+        const int64_t last = ((cap + 63) / 64) * 64 - 1;   // the allocation is padded to 64 rows
+        if (ri > last) ri = last;
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(rnorm + ri),
+                                         (lds_ptr_t)(stage0 + buf * STAGE_BYTES + TILE_BYTES), 4, 0, 0);
+    };
     auto stage_tile = [&](int64_t tile, int buf) {
-        char *dst = stage0 + buf * STAGE_BYTES;
-        const uint16_t *tbase = mem + (size_t)tile * EM_ROWS * D;
 #pragma unroll
-        for (int i = 0; i < PPW; ++i) {
-            const int p = wave * PPW + i;
-            if (p < PIECES) {
-                const int off = p * 1024 + lane * 16;
-                const int row = off / ROW_BYTES, cp = (off - row * ROW_BYTES) >> 4;
-                const int c = cp ^ (row & 15);
-                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(tbase + (size_t)row * D + c * 8),
-                                                 (lds_ptr_t)(dst + p * 1024), 16, 0, 0);
-            }
-        }
-        if (wave == EM_WAVES - 1) {  // 64 reciprocal norms (this tile's 32 + 32 more; the allocation is padded to 64)
-            int64_t ri = tile * EM_ROWS + lane;
-            const int64_t last = ((cap + 63) / 64) * 64 - 1;
-            if (ri > last) ri = last;
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(rnorm + ri), (lds_ptr_t)(dst + TILE_BYTES), 4, 0, 0);
-        }
+        for (int i = 0; i < PPW; ++i) stage_piece(tile, buf, i);
+        if (wave == EM_WAVES - 1) stage_norm(tile, buf);
     };
     static_assert(PIECES % EM_WAVES == 0, "every wave issues exactly PPW row pieces per tile (the counted waits rely on it)");
 
@@ -185,7 +202,16 @@ __global__ void __launch_bounds__(EM_THREADS, 1)
             wait_vmcnt<0>();
         }
         __builtin_amdgcn_s_barrier();  // every wave's pieces of this tile have landed; everyone is done with tile it-1
-        if (it + STAGES - 1 < my_tiles) stage_tile(tile + (int64_t)(STAGES - 1) * nbx, (int)((it + STAGES - 1) % STAGES));
+        // LDS-DMA of tile it + STAGES - 1: an idle wave issues its pieces at once; a computing wave spreads them over
+        // its MFMA batches below (an LDS-DMA instruction takes ~100 cycles to issue: issued as one block by all
+        // eight waves right after the barrier, nobody fed the matrix pipe for ~1 k cycles per tile)
+        const bool do_stage = it + STAGES - 1 < my_tiles;
+        const int64_t ntile = tile + (int64_t)(STAGES - 1) * nbx;
+        const int nbuf = (int)((it + STAGES - 1) % STAGES);
+        // (spreading them also over the 2 KS batches of an un-paired wave cost 15 %: those waves are LDS-read-bound and
+        // every extra instruction between their MFMA batches shows)
+        const bool spread = paired && active;
+        if (do_stage && !spread) stage_tile(ntile, nbuf);
         if (!active) continue;
         const unsigned tb = lds0 + buf * STAGE_BYTES;  // LDS byte address of this tile's image
         for (int rb = rb0; rb < rb1; ++rb) {
@@ -198,38 +224,60 @@ __global__ void __launch_bounds__(EM_THREADS, 1)
             u32x4 rn4;
             lds_read_b128<0>(rn4, tb + TILE_BYTES + (16 * rb + 4 * h) * 4);
             u32x4 e0, e1, e2, e3, o0, o1, o2, o3;  // even / odd batch of four A fragments
-            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 accs[NG];
+#pragma unroll
+            for (int u = 0; u < NG; ++u) accs[u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #define VM_ISSUE4(M, a, b, c, d)                 \
     lds_read_b128<256 * (M)>(a, base[0]);        \
     lds_read_b128<256 * (M)>(b, base[1]);        \
     lds_read_b128<256 * (M)>(c, base[2]);        \
     lds_read_b128<256 * (M)>(d, base[3]);
-#define VM_MMA4(M, a, b, c, d)                                                  \
-    acc = E::mfma16(__builtin_bit_cast(vec8, a), bq[4 * (M) + 0], acc);        \
-    acc = E::mfma16(__builtin_bit_cast(vec8, b), bq[4 * (M) + 1], acc);        \
-    acc = E::mfma16(__builtin_bit_cast(vec8, c), bq[4 * (M) + 2], acc);        \
-    acc = E::mfma16(__builtin_bit_cast(vec8, d), bq[4 * (M) + 3], acc);
+#define VM_MMA4(M, a, b, c, d)                                                     \
+    _Pragma("unroll") for (int u = 0; u < NG; ++u) {                             \
+        accs[u] = E::mfma16(__builtin_bit_cast(vec8, a), bq[u][4 * (M) + 0], accs[u]); \
+        accs[u] = E::mfma16(__builtin_bit_cast(vec8, b), bq[u][4 * (M) + 1], accs[u]); \
+        accs[u] = E::mfma16(__builtin_bit_cast(vec8, c), bq[u][4 * (M) + 2], accs[u]); \
+        accs[u] = E::mfma16(__builtin_bit_cast(vec8, d), bq[u][4 * (M) + 3], accs[u]); \
+    }
             // batch m + 1 is issued before batch m is waited for (counted lgkmcnt(4)): one batch always in flight
+            // NG = 2 has no registers for a second batch (2 x 96 hold the queries): the partner wave's 8 MFMAs per batch
+            // cover this wave's LDS round trip instead
 #define VM_STEP(M, ca, cb, cc, cd, na, nb, nc, nd)                       \
     if constexpr ((M) < KS) {                                             \
-        if constexpr ((M) + 1 < KS) {                                     \
+        if constexpr (DBUF && (M) + 1 < KS) {                             \
             VM_ISSUE4((M) + 1, na, nb, nc, nd)                            \
             VM_WAIT_LGKM4(4, ca, cb, cc, cd);                             \
         } else {                                                          \
+            if constexpr (!DBUF && (M) > 0) { VM_ISSUE4(M, ca, cb, cc, cd) } \
             VM_WAIT_LGKM4(0, ca, cb, cc, cd);                             \
         }                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                \
+        if (do_stage && spread) {                                         \
+            stage_piece(ntile, nbuf, (M));                                \
+            if (wave == EM_WAVES - 1 && (M) == KS - 1) stage_norm(ntile, nbuf); \
+        }                                                                 \
         VM_MMA4(M, ca, cb, cc, cd)                                        \
     }
             VM_ISSUE4(0, e0, e1, e2, e3)
-            VM_STEP(0, e0, e1, e2, e3, o0, o1, o2, o3)
-            VM_STEP(1, o0, o1, o2, o3, e0, e1, e2, e3)
-            VM_STEP(2, e0, e1, e2, e3, o0, o1, o2, o3)
-            VM_STEP(3, o0, o1, o2, o3, e0, e1, e2, e3)
-            VM_STEP(4, e0, e1, e2, e3, o0, o1, o2, o3)
-            VM_STEP(5, o0, o1, o2, o3, e0, e1, e2, e3)
-            VM_STEP(6, e0, e1, e2, e3, o0, o1, o2, o3)
-            VM_STEP(7, o0, o1, o2, o3, e0, e1, e2, e3)
+            if constexpr (DBUF) {
+                VM_STEP(0, e0, e1, e2, e3, o0, o1, o2, o3)
+                VM_STEP(1, o0, o1, o2, o3, e0, e1, e2, e3)
+                VM_STEP(2, e0, e1, e2, e3, o0, o1, o2, o3)
+                VM_STEP(3, o0, o1, o2, o3, e0, e1, e2, e3)
+                VM_STEP(4, e0, e1, e2, e3, o0, o1, o2, o3)
+                VM_STEP(5, o0, o1, o2, o3, e0, e1, e2, e3)
+                VM_STEP(6, e0, e1, e2, e3, o0, o1, o2, o3)
+                VM_STEP(7, o0, o1, o2, o3, e0, e1, e2, e3)
+            } else {
+                VM_STEP(0, e0, e1, e2, e3, e0, e1, e2, e3)
+                VM_STEP(1, e0, e1, e2, e3, e0, e1, e2, e3)
+                VM_STEP(2, e0, e1, e2, e3, e0, e1, e2, e3)
+                VM_STEP(3, e0, e1, e2, e3, e0, e1, e2, e3)
+                VM_STEP(4, e0, e1, e2, e3, e0, e1, e2, e3)
+                VM_STEP(5, e0, e1, e2, e3, e0, e1, e2, e3)
+                VM_STEP(6, e0, e1, e2, e3, e0, e1, e2, e3)
+                VM_STEP(7, e0, e1, e2, e3, e0, e1, e2, e3)
+            }
 #undef VM_STEP
 #undef VM_MMA4
 #undef VM_ISSUE4
@@ -241,139 +289,211 @@ __global__ void __launch_bounds__(EM_THREADS, 1)
                                   __builtin_bit_cast(float, rn2), __builtin_bit_cast(float, rn3)};
             const int64_t p0 = tile * EM_ROWS + 16 * rb + 4 * h;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int64_t p = p0 + j;
-                int64_t o64 = p - rv.head;
-                if (o64 < 0) o64 += rv.cap;
-                const int o = (int)o64;
-                const float sc = acc[j] * rnv[j];
-                const bool pass = p < rv.n && !better(ts, to, sc, o);  // at or above the cut
-                const unsigned long long m = __ballot(pass);
-                if (m) {  // wave-uniform, rare
-                    if (pending > EM_WBUF - 64) flush();
-                    if (pass) {
-                        const int idx = pending + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
-                                                                            __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-                        lds_write_b32(eb0 + idx * 4, __builtin_bit_cast(unsigned, sc));
-                        lds_write_b32(eb0 + (EM_WBUF + idx) * 4, (unsigned)o);
-                        lds_write_b32(eb0 + (2 * EM_WBUF + idx) * 4, (unsigned)myq);
+            for (int u = 0; u < NG; ++u) {
+                // fast reject of the whole 4 x 64 score block with one compare: the best of the lane's four scaled
+                // scores against the cut (rows past the end of the memory hold zeros or old rows: they can only make
+                // the test pass needlessly; validity, order and the tie rule are applied in the rare slow path)
+                const float s0 = accs[u][0] * rnv[0], s1 = accs[u][1] * rnv[1], s2 = accs[u][2] * rnv[2],
+                            s3 = accs[u][3] * rnv[3];
+                const float sv[4] = {s0, s1, s2, s3};
+                if (!thr_s) {
+                    // no cut (first pass of the cascade): EVERY score is a candidate - written straight to slot =
+                    // physical index of its row, no counter, no atomics (through the emission buffer this pass took 75 us
+                    // for 1024 rows: one flush with 64 atomics per ballot)
+                    const bool have = ts[u] != INFINITY;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int64_t p = p0 + j;
+                        int64_t o64 = p - rv.head;
+                        if (o64 < 0) o64 += rv.cap;
+                        if (have && p < rv.n && p < VM_EMIT_CAP) {  // slot = physical row index: dense in [0, n)
+                            cand_s[(size_t)myq[u] * VM_EMIT_CAP + p] = sv[j];
+                            cand_o[(size_t)myq[u] * VM_EMIT_CAP + p] = (int)o64;
+                        }
                     }
-                    pending += __popcll(m);
+                    continue;
+                }
+                const float best4 = fmaxf(fmaxf(s0, s1), fmaxf(s2, s3));
+                if (__ballot(best4 >= ts[u]) == 0ull) continue;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int64_t p = p0 + j;
+                    int64_t o64 = p - rv.head;
+                    if (o64 < 0) o64 += rv.cap;
+                    const int o = (int)o64;
+                    const float sc = sv[j];
+                    const bool pass = p < rv.n && !better(ts[u], to[u], sc, o);  // at or above the cut
+                    const unsigned long long m = __ballot(pass);
+                    if (m) {  // wave-uniform
+                        if (pending > EM_WBUF - 64) flush();
+                        if (pass) {
+                            const int idx = pending + __builtin_amdgcn_mbcnt_hi(
+                                                          (unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                            lds_write_b32(eb0 + idx * 4, __builtin_bit_cast(unsigned, sc));
+                            lds_write_b32(eb0 + (EM_WBUF + idx) * 4, (unsigned)o);
+                            lds_write_b32(eb0 + (2 * EM_WBUF + idx) * 4, (unsigned)myq[u]);
+                        }
+                        pending += __popcll(m);
+                    }
                 }
             }
         }
     }
     if (pending) flush();
+    if (!thr_s && bx == 0 && active && tid < 64 * EM_WAVES) {  // dense pass: candidate count = rows scanned
+#pragma unroll
+        for (int u = 0; u < NG; ++u)
+            if (ts[u] != INFINITY && h == 0)
+                cand_cnt[myq[u]] = (int)(rv.n < VM_EMIT_CAP ? rv.n : VM_EMIT_CAP);
+    }
 }
 
 // One block per query: candidate buffer -> ONE sorted list of the KL best (score desc, order asc), in the list layout
-// topk.hip's finalize kernel reads (nblk = 1).  mark[q] = 1 when the buffer overflowed or the ties at the KL-th place
-// outnumber what is ranked here: finalize then flags the query for the exhaustive redo.
+// topk.hip's finalize kernel reads (nblk = 1), and / or the query's next CUT = the KL-th best (cut cascade).
+// The KL-th largest score key is found by a 4-pass radix select (8 bits per pass: LDS histogram of the keys that match
+// the prefix, Hillis-Steele suffix sums over the 256 bins), then everything at or above it - all ties included - is
+// ranked by (score desc, order asc).  (Two earlier versions - a bitwise search with a block reduction per bit, KL
+// rounds of block arg-best - spent 18-24 us per launch in chains of dependent cross-lane shuffles.)
+// mark[q] = 1 when the buffer overflowed or more ties sit at the KL-th place than are ranked here: finalize then
+// flags the query for the exhaustive redo.
+constexpr int CP_SURV = 512;
 __global__ void __launch_bounds__(CP_THREADS)
     topk_compact_kernel(const int *__restrict__ cand_cnt, const float *__restrict__ cand_s,
-                        const int *__restrict__ cand_o, int KL, int q_pad, float *__restrict__ part_s,
-                        int *__restrict__ part_o, int *__restrict__ mark) {
-    __shared__ int wsum[CP_THREADS / 64];
+                        const int *__restrict__ cand_o, int KL, float *__restrict__ part_s, int *__restrict__ part_o,
+                        int *__restrict__ mark, float *__restrict__ cut_s, int *__restrict__ cut_o) {
+    __shared__ int hist[2][CP_THREADS];
     __shared__ float sv_s[CP_SURV];
     __shared__ int sv_o[CP_SURV];
-    __shared__ int nsurv;
+    __shared__ int nsurv, sel_digit, sel_rem;
     const int q = blockIdx.x, tid = threadIdx.x;
     const int cnt = cand_cnt[q];
     const int C = cnt < VM_EMIT_CAP ? cnt : VM_EMIT_CAP;
     unsigned key[CP_PER_THREAD];
-    int ord[CP_PER_THREAD];
-    float scv[CP_PER_THREAD];
 #pragma unroll
     for (int i = 0; i < CP_PER_THREAD; ++i) {
         const int c = tid + CP_THREADS * i;
-        const bool have = c < C;
-        const float s = have ? cand_s[(size_t)q * VM_EMIT_CAP + c] : 0.f;
-        const unsigned u = __builtin_bit_cast(unsigned, s);
-        key[i] = have ? ((u & 0x80000000u) ? ~u : (u | 0x80000000u)) : 0u;  // order-preserving; 0 = no entry
-        if (have && key[i] == 0u) key[i] = 1u;                              // (only -NaN maps to 0)
-        ord[i] = have ? cand_o[(size_t)q * VM_EMIT_CAP + c] : INT_MAX;
-        scv[i] = s;
-    }
-    if (tid == 0) nsurv = 0;
-    auto block_count = [&](auto pred) {
-        int c = 0;
-#pragma unroll
-        for (int i = 0; i < CP_PER_THREAD; ++i) c += pred(i) ? 1 : 0;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
-        __syncthreads();
-        if ((tid & 63) == 0) wsum[tid >> 6] = c;
-        __syncthreads();
-        return (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
-    };
-    const int want = C < KL ? C : KL;
-    unsigned tk = 0;  // largest key with count(key >= tk) >= want
-    if (want > 0) {
-        for (int bit = 31; bit >= 0; --bit) {
-            const unsigned cand = tk | (1u << bit);
-            if (block_count([&](int i) { return key[i] >= cand; }) >= want) tk = cand;
+        if (c < C) {
+            const unsigned u = __builtin_bit_cast(unsigned, cand_s[(size_t)q * VM_EMIT_CAP + c]);
+            const unsigned k = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // order-preserving
+            key[i] = k ? k : 1u;                                            // 0 is reserved for "no entry"
+        } else {
+            key[i] = 0u;
         }
     }
-    // survivors: everything above the KL-th key, plus ALL ties at it (their orders decide; ranked below)
-    const int n_ge = want > 0 ? block_count([&](int i) { return key[i] != 0u && key[i] >= tk; }) : 0;
-    const bool too_many = n_ge > CP_SURV;
-    __syncthreads();
+    if (tid == 0) nsurv = 0;
+    const int want = C < KL ? C : KL;
+    unsigned prefix = 0;       // the decided high bits of the want-th largest key
+    int remaining = want;      // its rank among the keys that share the prefix
+    if (want > 0) {
+#pragma unroll 1
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 24 - 8 * pass;
+            hist[0][tid] = 0;
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < CP_PER_THREAD; ++i) {
+                const bool in = key[i] != 0u && (pass == 0 || (key[i] >> (shift + 8)) == (prefix >> (shift + 8)));
+                if (in) atomicAdd(&hist[0][(key[i] >> shift) & 255u], 1);
+            }
+            __syncthreads();
+            // suffix sums S[t] = sum_{b >= t} hist[b], ping-pong between the two arrays
+            int cur = 0;
+#pragma unroll
+            for (int d = 1; d < CP_THREADS; d <<= 1) {
+                const int v = hist[cur][tid] + (tid + d < CP_THREADS ? hist[cur][tid + d] : 0);
+                hist[cur ^ 1][tid] = v;
+                __syncthreads();
+                cur ^= 1;
+            }
+            const int mine = hist[cur][tid];
+            const int above = tid + 1 < CP_THREADS ? hist[cur][tid + 1] : 0;
+            if (mine >= remaining && above < remaining) {  // exactly one bin
+                sel_digit = tid;
+                sel_rem = remaining - above;
+            }
+            __syncthreads();
+            prefix |= (unsigned)sel_digit << shift;
+            remaining = sel_rem;
+            __syncthreads();
+        }
+    }
+    const unsigned tk = prefix;  // the want-th largest key
 #pragma unroll
     for (int i = 0; i < CP_PER_THREAD; ++i) {
         if (want > 0 && key[i] != 0u && key[i] >= tk) {
             const int slot = atomicAdd(&nsurv, 1);
             if (slot < CP_SURV) {
-                sv_s[slot] = scv[i];
-                sv_o[slot] = ord[i];
+                const int c = tid + CP_THREADS * i;
+                sv_s[slot] = cand_s[(size_t)q * VM_EMIT_CAP + c];
+                sv_o[slot] = cand_o[(size_t)q * VM_EMIT_CAP + c];
             }
         }
     }
     __syncthreads();
-    const int S = nsurv < CP_SURV ? nsurv : CP_SURV;
+    const bool too_many = nsurv > CP_SURV;
+    const int S = too_many ? CP_SURV : nsurv;
     float *ps = part_s + (size_t)q * KL;
     int *po = part_o + (size_t)q * KL;
-    (void)q_pad;
     for (int i = tid; i < KL; i += CP_THREADS) {
         ps[i] = -INFINITY;
         po[i] = INT_MAX;
     }
+    if (tid == 0 && cut_s && want < KL) {  // fewer than KL candidates: no valid cut
+        cut_s[q] = -INFINITY;
+        cut_o[q] = INT_MAX;
+    }
     __syncthreads();
-    if (tid < S) {
-        const float s = sv_s[tid];
-        const int o = sv_o[tid];
+    for (int e = tid; e < S; e += CP_THREADS) {
+        const float s = sv_s[e];
+        const int o = sv_o[e];
         int rank = 0;
         for (int d = 0; d < S; ++d) rank += better(sv_s[d], sv_o[d], s, o) ? 1 : 0;
         if (rank < KL) {
             ps[rank] = s;
             po[rank] = o;
+            if (cut_s && rank == KL - 1) {
+                cut_s[q] = s;
+                cut_o[q] = o;
+            }
         }
     }
-    if (tid == 0) mark[q] = (cnt > VM_EMIT_CAP || too_many) ? 1 : 0;
+    if (tid == 0 && mark) mark[q] = (cnt > VM_EMIT_CAP || too_many) ? 1 : 0;
 }
 
-template <int DT, int KS>
+template <int DT, int KS, int NG>
 int launch_emit(vm_memory *m, const void *queries, int Q, const float *thr_s, const int *thr_o, int *cand_cnt,
-                float *cand_s, int *cand_o, hipStream_t st) {
+                float *cand_s, int *cand_o, int64_t row_limit, hipStream_t st) {
     constexpr int D = 128 * KS;
     constexpr int STAGES = KS <= 6 ? 3 : 2;
     const size_t lds = (size_t)STAGES * (EM_ROWS * 2 * D + 256) + (size_t)EM_WAVES * EM_WBUF * 12;
-    auto kern = topk_emit_kernel<DT, KS>;
+    auto kern = topk_emit_kernel<DT, KS, NG>;
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return vm_fail(m->ctx, VM_ERR_HIP, "emit LDS opt-in %zu: %s", lds, hipGetErrorString(e));
         attr = true;
     }
-    const int nsuper = (Q + EM_QPB - 1) / EM_QPB;
+    const int nsuper = (Q + EM_QPB * NG - 1) / (EM_QPB * NG);
     int nbx = m->ctx->num_cus / nsuper;
     if (nbx < 1) nbx = 1;
-    const int64_t ntiles = (m->cap + EM_ROWS - 1) / EM_ROWS;
+    const int64_t rows = m->cap < row_limit ? m->cap : row_limit;
+    const int64_t ntiles = (rows + EM_ROWS - 1) / EM_ROWS;
     if (nbx > ntiles) nbx = (int)ntiles;
     vm_prof_scope prof(m->ctx, VM_PROF_TOPK_SCAN, st);
     kern<<<nbx * nsuper, EM_THREADS, lds, st>>>(m->rows, m->rnorm32, (const uint16_t *)queries, m->d_total, m->cap,
-                                               m->ring, Q, thr_s, thr_o, cand_cnt, cand_s, cand_o, nsuper);
+                                               m->ring, Q, thr_s, thr_o, cand_cnt, cand_s, cand_o, nsuper, row_limit);
     VM_LAUNCH_CHECK(m->ctx);
     return VM_OK;
+}
+
+template <int DT, int KS>
+int launch_emit_ng(vm_memory *m, const void *queries, int Q, const float *thr_s, const int *thr_o, int *cand_cnt,
+                   float *cand_s, int *cand_o, int64_t row_limit, hipStream_t st) {
+    if constexpr (KS <= 4) {  // two query groups per wave need 2 x 16 KS registers for the queries alone: at
+        if (Q > EM_QPB)       // D = 768 that is 192 of 256 and the kernel spills (scratch traffic inside counted waits)
+            return launch_emit<DT, KS, 2>(m, queries, Q, thr_s, thr_o, cand_cnt, cand_s, cand_o, row_limit, st);
+    }
+    return launch_emit<DT, KS, 1>(m, queries, Q, thr_s, thr_o, cand_cnt, cand_s, cand_o, row_limit, st);
 }
 
 }  // namespace
@@ -396,11 +516,12 @@ size_t vm_topk_emit_workspace_bytes(int q_pad) {
 
 // cand_cnt must be zero when the scan starts (the caller memsets it on the stream)
 int vm_topk_emit_scan(vm_memory *m, const void *queries, int Q, const float *thr_s, const int *thr_o, int *cand_cnt,
-                      float *cand_s, int *cand_o, hipStream_t st) {
+                      float *cand_s, int *cand_o, int64_t row_limit, hipStream_t st) {
     const int ks = m->D / 128;
-#define GO(KSV)                                                                                                  \
-    return m->dtype == VM_F16 ? launch_emit<VM_F16, KSV>(m, queries, Q, thr_s, thr_o, cand_cnt, cand_s, cand_o, st) \
-                              : launch_emit<VM_BF16, KSV>(m, queries, Q, thr_s, thr_o, cand_cnt, cand_s, cand_o, st)
+#define GO(KSV)                                                                                                   \
+    return m->dtype == VM_F16                                                                                     \
+               ? launch_emit_ng<VM_F16, KSV>(m, queries, Q, thr_s, thr_o, cand_cnt, cand_s, cand_o, row_limit, st) \
+               : launch_emit_ng<VM_BF16, KSV>(m, queries, Q, thr_s, thr_o, cand_cnt, cand_s, cand_o, row_limit, st)
     switch (ks) {
         case 1: GO(1);
         case 2: GO(2);
@@ -412,10 +533,10 @@ int vm_topk_emit_scan(vm_memory *m, const void *queries, int Q, const float *thr
 #undef GO
 }
 
-int vm_topk_emit_compact(vm_memory *m, int Q, int KL, int q_pad, const int *cand_cnt, const float *cand_s,
-                         const int *cand_o, float *part_s, int *part_o, int *mark, hipStream_t st) {
+int vm_topk_emit_compact(vm_memory *m, int Q, int KL, const int *cand_cnt, const float *cand_s, const int *cand_o,
+                         float *part_s, int *part_o, int *mark, float *cut_s, int *cut_o, hipStream_t st) {
     vm_prof_scope prof(m->ctx, VM_PROF_TOPK_FINALIZE, st);
-    topk_compact_kernel<<<Q, CP_THREADS, 0, st>>>(cand_cnt, cand_s, cand_o, KL, q_pad, part_s, part_o, mark);
+    topk_compact_kernel<<<Q, CP_THREADS, 0, st>>>(cand_cnt, cand_s, cand_o, KL, part_s, part_o, mark, cut_s, cut_o);
     VM_LAUNCH_CHECK(m->ctx);
     return VM_OK;
 }
