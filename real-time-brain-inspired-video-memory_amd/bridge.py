@@ -82,20 +82,25 @@ def export_nodes(memory, embedding_model: Optional[str] = None, batch_id: Option
     nodes = []
     for r, emb in zip(range(lo, hi), rows_to_lists(rows, memory.dtype_name)):
         meta = memory.meta_of(r) or {}
-        props = {"id": memory.id_of(r), "content": meta.get("content"), "embedding": emb}
+        # property keys of the reference's own export (data/exports/mvp_...json, pinned by
+        # tests/golden/export_excerpt.json): batch_id, created_at, id, content (+ embedding, embedding_model when the
+        # chunk was stored with one, neo4j_handler.py:229-242)
+        props = {"batch_id": meta.get("batch_id", batch_id), "created_at": meta.get("created_at"),
+                 "id": memory.id_of(r), "content": meta.get("content"), "embedding": emb}
         if "time" in meta:
             props["time"] = meta["time"]
         if embedding_model is not None:
             props["embedding_model"] = embedding_model  # neo4j_handler.py:235
-        if batch_id is not None:
-            props["batch_id"] = batch_id                # neo4j_handler.py:234
         nodes.append({"name": None, "labels": ["Chunk"], "properties": props})
     return nodes
 
 
 def write_export(memory, path: str, **kw) -> str:
-    data = {"graph_uuid": memory.graph_uuid, "nodes": export_nodes(memory, **kw), "relationships": [],
-            "export_format_version": EXPORT_FORMAT_VERSION}
+    import uuid
+    # same keys, same order as GraphExporter.export_graph writes them (src/components/graph_exporter.py:61-67); the
+    # reference fills export_timestamp with a fresh uuid4 string (:63, "Could use actual timestamp")
+    data = {"graph_uuid": memory.graph_uuid, "export_timestamp": str(uuid.uuid4()),
+            "nodes": export_nodes(memory, **kw), "relationships": [], "export_format_version": EXPORT_FORMAT_VERSION}
     with open(path, "w", encoding="utf-8") as f:
         json.dump(data, f, indent=2, ensure_ascii=False)
     return path
@@ -125,7 +130,8 @@ def load_export(memory, source, graph_uuid: Optional[str] = None) -> Tuple[int, 
             continue
         ids.append(cid)
         rows.append(emb)
-        metas.append({"content": props.get("content"), "time": props.get("time")})
+        metas.append({"content": props.get("content"), "time": props.get("time"), "batch_id": props.get("batch_id"),
+                      "created_at": props.get("created_at")})
     if rows:
         memory.append(rows, ids=ids, meta=metas)
     return len(ids), skipped

@@ -196,7 +196,9 @@ class FrameEmbeddingExtractor:
                     for s_row, r_row in zip(scores.cpu().tolist(), rows.cpu().tolist()):
                         similar.append([(self.memory.id_of(r), float(s)) for s, r in zip(s_row, r_row) if r >= 0])
                 ids = [f"{run_id}_{chunk_idx}_{i}" for i in range(nframes)]  # pre_llm_injector.py:91 id scheme
-                first = self.memory.append(emb, ids=ids, meta=[{"time": time_str, "content": None}] * nframes)
+                created = time.strftime("%Y-%m-%dT%H:%M:%S+00:00", time.gmtime())   # Chunk.created_at of the export
+                first = self.memory.append(emb, ids=ids, meta=[{"time": time_str, "content": None,
+                                                                "batch_id": chunk_idx, "created_at": created}] * nframes)
                 torch.cuda.synchronize(self.encoder.device)
                 chunk_time = time.perf_counter() - chunk_start
                 results.append({

@@ -88,7 +88,7 @@ def test_export_round_trip_is_identity(tmp_path):
     n, skipped = bridge.load_export(back, data)
     assert n == 5 and skipped == [] and back.ids == mem.ids
     assert np.array_equal(back.rows_host()[1], mem.rows_host()[1])  # bit-identical rows
-    assert back.meta[2] == {"content": "c2", "time": "00:00-00:02"}
+    assert back.meta[2] == {"content": "c2", "time": "00:00-00:02", "batch_id": 3, "created_at": None}
     assert bridge.export_nodes(back, embedding_model="vit-b16", batch_id=3) == json.load(open(path))["nodes"]
 
 
@@ -107,3 +107,49 @@ def test_bf16_rows_to_lists_matches_torch():
     t = torch.randn(7, 9, generator=torch.Generator().manual_seed(3)).to(torch.bfloat16)
     raw = t.view(torch.int16).numpy().view(np.uint16)
     assert bridge.rows_to_lists(raw, "bf16") == t.to(torch.float64).tolist()
+
+
+def test_export_format_is_pinned_to_the_reference_artifact(tmp_path):
+    """tests/golden/export_excerpt.json is cut (tests/golden/make_export_golden.py) out of the ONE export the
+    reference ships, data/exports/mvp_93e9c82e-...json: 326 Chunk nodes, none with an embedding (the MVP run stored
+    its chunks through the no-embedding branch, src/components/neo4j_handler.py:243-253).
+      * load_export must accept it: nothing embedded -> nothing appended, nothing skipped, nothing raised;
+      * write_export must emit the same top-level keys in the same order (src/components/graph_exporter.py:61-67,
+        export_timestamp included) and Chunk nodes of the same shape (:97-101) whose property keys cover the
+        reference's (batch_id, created_at, id, content)."""
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    fx = json.load(open(os.path.join(here, "golden", "export_excerpt.json"), encoding="utf-8"))
+    ref, stats = fx["excerpt"], fx["stats"]
+    assert stats["source_chunk_nodes"] == 326 and stats["source_chunks_with_embedding"] == 0
+    assert list(ref) == ["graph_uuid", "export_timestamp", "nodes", "relationships", "export_format_version"]
+    assert ref["export_format_version"] == bridge.EXPORT_FORMAT_VERSION
+
+    mem = HostMemory(8, graph_uuid=ref["graph_uuid"])
+    n, skipped = bridge.load_export(mem, ref)
+    assert (n, skipped, mem.ids) == (0, [], [])
+    with pytest.raises(ValueError):
+        bridge.load_export(HostMemory(8, graph_uuid="another-graph"), ref)
+
+    ref_chunk = next(x for x in ref["nodes"] if "Chunk" in x["labels"])
+    assert set(ref_chunk) == {"name", "labels", "properties"} and ref_chunk["name"] is None
+    assert set(ref_chunk["properties"]) == set(stats["chunk_property_keys"]) == {"batch_id", "created_at", "id", "content"}
+
+    v = _vecs(2, 8, seed=4)
+    mem.append(v, ids=[ref_chunk["properties"]["id"], "x_0_1"],
+               meta=[{"content": ref_chunk["properties"]["content"], "batch_id": ref_chunk["properties"]["batch_id"],
+                      "created_at": ref_chunk["properties"]["created_at"]}, {"content": "b"}])
+    out = json.load(open(bridge.write_export(mem, str(tmp_path / "out.json")), encoding="utf-8"))
+    assert list(out) == list(ref)                                     # same keys, same order
+    assert isinstance(out["export_timestamp"], str) and len(out["export_timestamp"]) == len(ref["export_timestamp"])
+    node = out["nodes"][0]
+    assert set(node) == set(ref_chunk) and node["labels"] == ref_chunk["labels"] and node["name"] is None
+    assert set(ref_chunk["properties"]) <= set(node["properties"])     # + embedding, which this path adds
+    for k in ("batch_id", "created_at", "id", "content"):
+        assert node["properties"][k] == ref_chunk["properties"][k]
+    # and the file round-trips through the importer: rows and metadata identical
+    back = HostMemory(8, graph_uuid=ref["graph_uuid"])
+    assert bridge.load_export(back, out)[0] == 2
+    assert np.array_equal(back.rows_host()[1], mem.rows_host()[1]) and back.ids == mem.ids
+    assert back.meta[0]["batch_id"] == ref_chunk["properties"]["batch_id"]
+    assert back.meta[0]["created_at"] == ref_chunk["properties"]["created_at"]

@@ -315,3 +315,45 @@ def test_emit_scan_overflow_and_tie_floods_fall_back_to_the_exhaustive_redo():
     assert np.array_equal(s.cpu().numpy(), want_s)
     assert r[7].tolist() == sorted(flood.tolist())[:k]
     assert 2 <= mem.uncertified_count <= 4
+
+
+def test_full_size_properties_1m_rows_bf16_k20():
+    """BASELINE configs[2] size (1M x 1024 bf16, top-20): size-independent properties instead of an oracle pass -
+    planted self-matches first with score 1, strictly ordered distinct rows, the returned scores are the exact
+    reference cosines of the returned rows, sharding invariance (top-k(whole) == merge(top-k(halves))), agreement with
+    the exhaustive kernel on one query - for Q = 16 (list scan) and Q = 64 (emit scan)."""
+    D, M, k = 1024, 1_000_000, 20
+    g = torch.Generator(device="cuda").manual_seed(4321)
+    from vidmem.memory import EmbeddingMemory, topk_merge
+    mem = EmbeddingMemory(M, D, "bf16")
+    halves = [EmbeddingMemory(M // 2, D, "bf16") for _ in range(2)]
+    keep = []
+    for lo in range(0, M, 250_000):
+        x = torch.randn((250_000, D), generator=g, device="cuda", dtype=torch.float32)
+        x = (x / x.norm(dim=1, keepdim=True)).to(torch.bfloat16)
+        mem.append(x)
+        for part in range(2):
+            halves[part].append(x[part::2])        # lo is even: global row r lives in half r % 2 at local row r // 2
+        keep.append(x[:8].clone())
+    planted = [3, 500_000, 999_999, 250_001]
+    rows_of = {3: keep[0][3], 500_000: keep[2][0], 250_001: keep[1][1]}
+    rows_of[999_999] = mem.rows_tensor()[999_999].clone()
+    for Q in (16, 64):
+        q = torch.randn((Q, D), generator=g, device="cuda", dtype=torch.float32).to(torch.bfloat16)
+        for i, row in enumerate(planted):
+            q[i] = rows_of[row]
+        mem.reset_uncertified()
+        s, r = mem.topk(q, k)
+        s_np, r_np = s.cpu().numpy(), r.cpu().numpy()
+        for i, row in enumerate(planted):
+            assert r_np[i, 0] == row and abs(s_np[i, 0] - 1.0) < 1e-12, (Q, i)
+        assert (np.diff(s_np, axis=1) <= 0).all() and (r_np >= 0).all()
+        assert all(len(set(r_np[i].tolist())) == k for i in range(Q))
+        ex = mem.cosine_exact(q[5:6], mem.rows_tensor()[r[5]]).cpu().numpy()
+        assert np.array_equal(ex[0], s_np[5])
+        parts = [h.topk(q, k, row_stride=2, row_offset=p) for p, h in enumerate(halves)]
+        ms, mr = topk_merge(mem.ctx, torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
+        assert np.array_equal(mr.cpu().numpy(), r_np) and np.array_equal(ms.cpu().numpy(), s_np)
+        s2, r2 = mem.topk(q[6:7], k, exact=True)
+        assert np.array_equal(r2.cpu().numpy(), r_np[6:7]) and np.array_equal(s2.cpu().numpy(), s_np[6:7])
+        assert mem.uncertified_count == 0
