@@ -42,14 +42,20 @@ __device__ __forceinline__ float4 load4_16(const uint16_t *p) {
 }
 
 // Residual add + LayerNorm, one wave per token row, H = 256 * VPL, lane owns 4-element chunks lane + 64*i.
-//   x_new = x32[row] + delta16[row]        (delta = the previous GEMM's 16-bit output; skipped when delta == null)
-//   x32[row] = x_new                       (fp32 residual stream stays in HBM / Infinity Cache)
+//   x_new = (x32[row] + dA[row]) + dB[row] (the 16-bit outputs of the residual branches not yet folded into x32; either
+//                                           may be null)
+//   x32[row] = x_new                       only when write_x: the pass in front of the attention block folds BOTH pending
+//                                           branch outputs (projection, FC2) into the fp32 stream; the pass in front of
+//                                           the MLP only reads x32 + projection and leaves the fold to the next one
+//                                           (22 instead of 24 bytes per element and layer: the kernel runs at the HBM
+//                                           roofline, so only fewer bytes make it faster)
 //   out16[row] = LN(x_new) * gamma + beta  (the next GEMM's A operand)
 // Two-pass statistics in registers (mean, then mean of squared deviations), as the oracle computes them.
 // The GEMMs therefore never read the residual: their epilogues are pure 16-bit stores.
 template <int DT, int VPL, int RPW>  // RPW rows per wave: all loads of both rows are in flight before the first use
 __global__ void __launch_bounds__(256) resid_layernorm_kernel(float *__restrict__ x32,
                                                               const uint16_t *__restrict__ delta16,
+                                                              const uint16_t *__restrict__ deltaB16, int write_x,
                                                               const float *__restrict__ gamma,
                                                               const float *__restrict__ beta, float eps,
                                                               uint16_t *__restrict__ out16, int rows, int H) {
@@ -59,6 +65,7 @@ __global__ void __launch_bounds__(256) resid_layernorm_kernel(float *__restrict_
     if (row0 >= rows) return;
     float4 v[RPW][VPL];
     float4 d[RPW][VPL];
+    float4 e[RPW][VPL];
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
         const int row = row0 + r < rows ? row0 + r : rows - 1;
@@ -69,6 +76,11 @@ __global__ void __launch_bounds__(256) resid_layernorm_kernel(float *__restrict_
             const uint16_t *dr = delta16 + (size_t)row * H;
 #pragma unroll
             for (int i = 0; i < VPL; ++i) d[r][i] = load4_16<VM_F16>(dr + 4 * (lane + 64 * i));  // EPI_DELTA16: always fp16
+        }
+        if (deltaB16) {
+            const uint16_t *er = deltaB16 + (size_t)row * H;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) e[r][i] = load4_16<VM_F16>(er + 4 * (lane + 64 * i));
         }
     }
     float4 g4[VPL], b4[VPL];
@@ -82,15 +94,27 @@ __global__ void __launch_bounds__(256) resid_layernorm_kernel(float *__restrict_
         const int row = row0 + r;
         if (row >= rows) break;
         if (delta16) {
-            float4 *xr = reinterpret_cast<float4 *>(x32 + (size_t)row * H);
 #pragma unroll
             for (int i = 0; i < VPL; ++i) {
                 v[r][i].x += d[r][i].x;
                 v[r][i].y += d[r][i].y;
                 v[r][i].z += d[r][i].z;
                 v[r][i].w += d[r][i].w;
-                xr[lane + 64 * i] = v[r][i];
             }
+        }
+        if (deltaB16) {  // second, later branch output: added after the first, as the unfused sequence does
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                v[r][i].x += e[r][i].x;
+                v[r][i].y += e[r][i].y;
+                v[r][i].z += e[r][i].z;
+                v[r][i].w += e[r][i].w;
+            }
+        }
+        if (write_x) {
+            float4 *xr = reinterpret_cast<float4 *>(x32 + (size_t)row * H);
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) xr[lane + 64 * i] = v[r][i];
         }
         float sum = 0.f;
 #pragma unroll
@@ -167,6 +191,7 @@ __global__ void __launch_bounds__(256) embed_kernel(const uint16_t *__restrict__
 // W[proj_dim, H] (16-bit weights, 16-bit rounded input, fp32 accumulate), optional L2 normalisation, cast to 16 bit.
 template <int DT>
 __global__ void __launch_bounds__(256) pool_kernel(const float *__restrict__ x, const uint16_t *__restrict__ delta16,
+                                                   const uint16_t *__restrict__ deltaB16,
                                                    const float *__restrict__ gamma, const float *__restrict__ beta,
                                                    float eps, const uint16_t *__restrict__ proj_w, int proj_dim, int l2,
                                                    uint16_t *__restrict__ out, int T, int H) {
@@ -178,6 +203,7 @@ __global__ void __launch_bounds__(256) pool_kernel(const float *__restrict__ x, 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float *row = x + (size_t)blockIdx.x * T * H;
     const uint16_t *drow = delta16 + (size_t)blockIdx.x * T * H;
+    const uint16_t *erow = deltaB16 + (size_t)blockIdx.x * T * H;
     auto block_sum = [&](float v) {
         v = wave_sum(v);
         __syncthreads();
@@ -187,7 +213,8 @@ __global__ void __launch_bounds__(256) pool_kernel(const float *__restrict__ x, 
     };
     float s = 0.f;
     for (int i = tid; i < H; i += 256) {
-        const float v = row[i] + vm_elem<VM_F16>::to_float(drow[i]);  // EPI_DELTA16: always fp16
+        // the last layer's two branch outputs (EPI_DELTA16: always fp16), in branch order
+        const float v = (row[i] + vm_elem<VM_F16>::to_float(drow[i])) + vm_elem<VM_F16>::to_float(erow[i]);
         y[i] = v;
         s += v;
     }
@@ -235,14 +262,15 @@ __global__ void __launch_bounds__(256) pool_kernel(const float *__restrict__ x, 
         default: return vm_fail(ctx, VM_ERR_UNSUPPORTED, "row width %d (need 256..1024, %%256)", H); \
     }
 
-int vm_resid_layernorm(vm_ctx *ctx, int dtype, float *x32, const uint16_t *delta16, const float *gamma,
-                       const float *beta, float eps, uint16_t *out16, int rows, int H, hipStream_t st) {
+int vm_resid_layernorm(vm_ctx *ctx, int dtype, float *x32, const uint16_t *delta16, const uint16_t *deltaB16,
+                       int write_x, const float *gamma, const float *beta, float eps, uint16_t *out16, int rows, int H,
+                       hipStream_t st) {
     constexpr int RPW = 2;
     const int blocks = (rows + 4 * RPW - 1) / (4 * RPW);
     if (H % 256 != 0) return vm_fail(ctx, VM_ERR_UNSUPPORTED, "row width %d", H);
     vm_prof_scope prof(ctx, VM_PROF_LAYERNORM, st);
-#define RLN16(V) resid_layernorm_kernel<VM_F16, V, RPW><<<blocks, 256, 0, st>>>(x32, delta16, gamma, beta, eps, out16, rows, H)
-#define RLNB16(V) resid_layernorm_kernel<VM_BF16, V, RPW><<<blocks, 256, 0, st>>>(x32, delta16, gamma, beta, eps, out16, rows, H)
+#define RLN16(V) resid_layernorm_kernel<VM_F16, V, RPW><<<blocks, 256, 0, st>>>(x32, delta16, deltaB16, write_x, gamma, beta, eps, out16, rows, H)
+#define RLNB16(V) resid_layernorm_kernel<VM_BF16, V, RPW><<<blocks, 256, 0, st>>>(x32, delta16, deltaB16, write_x, gamma, beta, eps, out16, rows, H)
     if (dtype == VM_F16) {
         VM_VPL_SWITCH(H, RLN16)
     } else {
@@ -272,15 +300,15 @@ int vm_embed(vm_ctx *ctx, int dtype, const uint16_t *patch16, const float *cls, 
     return VM_OK;
 }
 
-int vm_pool(vm_ctx *ctx, int dtype, const float *x, const uint16_t *delta16, const float *gamma, const float *beta,
-            float eps, const uint16_t *proj_w, int proj_dim, int l2, uint16_t *out, int B, int T, int H,
-            hipStream_t st) {
+int vm_pool(vm_ctx *ctx, int dtype, const float *x, const uint16_t *delta16, const uint16_t *deltaB16,
+            const float *gamma, const float *beta, float eps, const uint16_t *proj_w, int proj_dim, int l2, uint16_t *out,
+            int B, int T, int H, hipStream_t st) {
     const size_t lds = (size_t)(H + (proj_dim > 0 ? proj_dim : 0)) * 4;
     vm_prof_scope prof(ctx, VM_PROF_POOL, st);
     if (dtype == VM_F16)
-        pool_kernel<VM_F16><<<B, 256, lds, st>>>(x, delta16, gamma, beta, eps, proj_w, proj_dim, l2, out, T, H);
+        pool_kernel<VM_F16><<<B, 256, lds, st>>>(x, delta16, deltaB16, gamma, beta, eps, proj_w, proj_dim, l2, out, T, H);
     else
-        pool_kernel<VM_BF16><<<B, 256, lds, st>>>(x, delta16, gamma, beta, eps, proj_w, proj_dim, l2, out, T, H);
+        pool_kernel<VM_BF16><<<B, 256, lds, st>>>(x, delta16, deltaB16, gamma, beta, eps, proj_w, proj_dim, l2, out, T, H);
     VM_LAUNCH_CHECK(ctx);
     return VM_OK;
 }
@@ -443,7 +471,7 @@ static int micro_batch_of(const vm_encoder *e, int B) {
 
 struct Ws {
     float *x32;                            // fp32 residual stream [rows, H]
-    uint16_t *a16, *d16, *qkv16, *mlp16;   // LN out / attention ctx, residual-branch output, QKV, MLP hidden
+    uint16_t *a16, *d16, *e16, *qkv16, *mlp16;   // LN out / attention ctx, projection out (+ patch rows), FC2 out, QKV, MLP hidden
     size_t bytes;
 };
 static Ws carve(const vm_encoder *e, int mb, void *base) {
@@ -458,6 +486,7 @@ static Ws carve(const vm_encoder *e, int mb, void *base) {
     w.x32 = (float *)take(rows * H * 4);
     w.a16 = (uint16_t *)take(rows * H * 2);
     w.d16 = (uint16_t *)take(rows * H * 2);
+    w.e16 = (uint16_t *)take(rows * H * 2);
     w.qkv16 = (uint16_t *)take(rows * 3 * H * 2);
     w.mlp16 = (uint16_t *)take(rows * M * 2);
     w.bytes = off;
@@ -502,24 +531,30 @@ extern "C" int vm_encode(vm_encoder *e, const void *patches, int B, void *out_em
                          ws.d16, nb * P, H, e->patch_k, EPI_DELTA16, VM_PROF_GEMM_PATCH)) != VM_OK) return rc;
         if ((rc = vm_embed(ctx, dt, ws.d16, e->cls, e->pos, e->pre_g, e->pre_b, d.ln_eps, d.pre_ln, ws.x32, nb, T, H,
                            st)) != VM_OK) return rc;
-        const uint16_t *delta = nullptr;  // 16-bit output of the previous residual branch, not yet added to x32
+        // Branch outputs not yet folded into x32: the projection's (ws.d16) and FC2's (ws.e16) of the PREVIOUS layer.
+        const uint16_t *pend_proj = nullptr, *pend_fc2 = nullptr;
         for (int l = 0; l < d.layers; ++l) {
             const LayerW &w = e->layers[l];
-            if ((rc = vm_resid_layernorm(ctx, dt, ws.x32, delta, w.ln1_g, w.ln1_b, d.ln_eps, ws.a16, rows, H, st)) != VM_OK) return rc;
+            // x32 += proj(l-1) + fc2(l-1), written back once; a16 = LN1(x32)
+            if ((rc = vm_resid_layernorm(ctx, dt, ws.x32, pend_proj, pend_fc2, pend_proj != nullptr, w.ln1_g, w.ln1_b,
+                                         d.ln_eps, ws.a16, rows, H, st)) != VM_OK) return rc;
             g_head_major = 1;  // q/k/v of one head as contiguous [rows, 64] blocks: attention streams whole KiB
             rc = gemm16(ws.a16, H, w.qkv_w, w.qkv_b, ws.qkv16, rows, 3 * H, H, EPI_STORE16, VM_PROF_GEMM_QKV);
             g_head_major = 0;
             if (rc != VM_OK) return rc;
             if ((rc = vm_attention(ctx, dt, ws.qkv16, ws.a16, nb, T, d.heads, st)) != VM_OK) return rc;
             if ((rc = gemm16(ws.a16, H, w.proj_w, w.proj_b, ws.d16, rows, H, H, EPI_DELTA16, VM_PROF_GEMM_RESID)) != VM_OK) return rc;
-            if ((rc = vm_resid_layernorm(ctx, dt, ws.x32, ws.d16, w.ln2_g, w.ln2_b, d.ln_eps, ws.a16, rows, H, st)) != VM_OK) return rc;
+            // a16 = LN2(x32 + proj(l)); x32 itself is NOT rewritten here: the next LN1 (or the pool) folds both
+            if ((rc = vm_resid_layernorm(ctx, dt, ws.x32, ws.d16, nullptr, 0, w.ln2_g, w.ln2_b, d.ln_eps, ws.a16, rows,
+                                         H, st)) != VM_OK) return rc;
             if ((rc = gemm16(ws.a16, H, w.fc1_w, w.fc1_b, ws.mlp16, rows, d.mlp, H, act_epi, VM_PROF_GEMM_ACT)) != VM_OK) return rc;
-            if ((rc = gemm16(ws.mlp16, d.mlp, w.fc2_w, w.fc2_b, ws.d16, rows, H, d.mlp, EPI_DELTA16, VM_PROF_GEMM_RESID)) != VM_OK) return rc;
-            delta = ws.d16;
+            if ((rc = gemm16(ws.mlp16, d.mlp, w.fc2_w, w.fc2_b, ws.e16, rows, H, d.mlp, EPI_DELTA16, VM_PROF_GEMM_RESID)) != VM_OK) return rc;
+            pend_proj = ws.d16;
+            pend_fc2 = ws.e16;
         }
         uint16_t *dst = (uint16_t *)out_emb + (size_t)b0 * e->out_dim;
-        if ((rc = vm_pool(ctx, dt, ws.x32, delta, e->ln_g, e->ln_b, d.ln_eps, e->proj_w, d.proj_dim, l2_normalise, dst,
-                          nb, T, H, st)) != VM_OK)
+        if ((rc = vm_pool(ctx, dt, ws.x32, pend_proj, pend_fc2, e->ln_g, e->ln_b, d.ln_eps, e->proj_w, d.proj_dim,
+                          l2_normalise, dst, nb, T, H, st)) != VM_OK)
             return rc;
     }
     return VM_OK;

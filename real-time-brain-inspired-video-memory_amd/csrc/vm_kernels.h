@@ -35,13 +35,15 @@ int vm_gemm(vm_ctx *ctx, int dtype, const GemmArgs &g, int epi, hipStream_t st);
 int vm_attention(vm_ctx *ctx, int dtype, const uint16_t *qkv, uint16_t *ctx_out, int B, int T, int heads,
                  hipStream_t st);
 
-// x32[row] += delta16[row] (skipped when delta16 == null); out16[row] = LayerNorm(x32[row]) * gamma + beta
-int vm_resid_layernorm(vm_ctx *ctx, int dtype, float *x32, const uint16_t *delta16, const float *gamma,
-                       const float *beta, float eps, uint16_t *out16, int rows, int H, hipStream_t st);
+// v = (x32[row] + delta16[row]) + deltaB16[row] (fp16 whatever `dtype`: EPI_DELTA16; either may be null);
+// x32[row] = v when write_x; out16[row] = LayerNorm(v) * gamma + beta
+int vm_resid_layernorm(vm_ctx *ctx, int dtype, float *x32, const uint16_t *delta16, const uint16_t *deltaB16,
+                       int write_x, const float *gamma, const float *beta, float eps, uint16_t *out16, int rows, int H,
+                       hipStream_t st);
 // x32[frame*T + tok] = (tok ? patch16[frame*(T-1) + tok-1] : cls) + pos[tok], then the optional pre-LayerNorm
 int vm_embed(vm_ctx *ctx, int dtype, const uint16_t *patch16, const float *cls, const float *pos, const float *pre_g,
              const float *pre_b, float eps, int pre_ln, float *x32, int B, int T, int H, hipStream_t st);
-// CLS row (x32 + delta16) -> final LayerNorm, optional projection, optional L2 normalisation, cast
-int vm_pool(vm_ctx *ctx, int dtype, const float *x, const uint16_t *delta16, const float *gamma, const float *beta,
-            float eps, const uint16_t *proj_w, int proj_dim, int l2, uint16_t *out, int B, int T, int H,
-            hipStream_t st);
+// CLS row ((x32 + delta16) + deltaB16) -> final LayerNorm, optional projection, optional L2 normalisation, cast
+int vm_pool(vm_ctx *ctx, int dtype, const float *x, const uint16_t *delta16, const uint16_t *deltaB16,
+            const float *gamma, const float *beta, float eps, const uint16_t *proj_w, int proj_dim, int l2, uint16_t *out,
+            int B, int T, int H, hipStream_t st);
