@@ -146,7 +146,10 @@ __global__ void __launch_bounds__(EM_THREADS, 1)
     // linear image; the source chunk is chunk' ^ (row & 15) (swizzle on the source address, the reads apply it again)
     auto stage_piece = [&](int64_t tile, int buf, int i) {   // i-th of this wave's PPW row pieces of a tile
         const int p = wave * PPW + i;
-        const int off = p * 1024 + lane * 16;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));  // recompute the per-lane source offset at every call: hoisted out of the tile loop
+                                      // the PPW 64-bit offsets cost 2 PPW registers the two-group variant does not have
+        const int off = p * 1024 + ln * 16;
         const int row = off / ROW_BYTES, cp = (off - row * ROW_BYTES) >> 4;
         const int c = cp ^ (row & 15);
         __builtin_amdgcn_global_load_lds((gbl_ptr_t)(mem + ((size_t)tile * EM_ROWS + row) * D + c * 8),
@@ -222,7 +225,7 @@ __global__ void __launch_bounds__(EM_THREADS, 1)
 #pragma unroll
             for (int t = 0; t < 4; ++t) base[t] = rowa + (((4 * t + h) ^ r16) << 4);
             u32x4 rn4;
-            lds_read_b128<0>(rn4, tb + TILE_BYTES + (16 * rb + 4 * h) * 4);
+            if constexpr (NG == 1) lds_read_b128<0>(rn4, tb + TILE_BYTES + (16 * rb + 4 * h) * 4);
             u32x4 e0, e1, e2, e3, o0, o1, o2, o3;  // even / odd batch of four A fragments
             f32x4 accs[NG];
 #pragma unroll
@@ -281,6 +284,10 @@ __global__ void __launch_bounds__(EM_THREADS, 1)
 #undef VM_STEP
 #undef VM_MMA4
 #undef VM_ISSUE4
+            if constexpr (NG == 2) {  // no register to keep the norms live across the batches: fetched here
+                lds_read_b128<0>(rn4, tb + TILE_BYTES + (16 * rb + 4 * h) * 4);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rn4));
+            }
             // acc[j] = <row tile*32 + 16 rb + 4 h + j , query myq>; rn4 landed before the first batch (in-order queue)
             // (elements copied out first: __builtin_bit_cast on an ext-vector ELEMENT expression reads element 0 for
             // every element with this hipcc - all four rows were scaled by rn4.x)
@@ -489,8 +496,8 @@ int launch_emit(vm_memory *m, const void *queries, int Q, const float *thr_s, co
 template <int DT, int KS>
 int launch_emit_ng(vm_memory *m, const void *queries, int Q, const float *thr_s, const int *thr_o, int *cand_cnt,
                    float *cand_s, int *cand_o, int64_t row_limit, hipStream_t st) {
-    if constexpr (KS <= 4) {  // two query groups per wave need 2 x 16 KS registers for the queries alone: at
-        if (Q > EM_QPB)       // D = 768 that is 192 of 256 and the kernel spills (scratch traffic inside counted waits)
+    if constexpr (KS <= 6) {  // two query groups per wave need 2 x 16 KS registers for the queries alone (192 of 256 at
+        if (Q > EM_QPB)       // D = 768: checked spill-free with -Rpass-analysis=kernel-resource-usage)
             return launch_emit<DT, KS, 2>(m, queries, Q, thr_s, thr_o, cand_cnt, cand_s, cand_o, row_limit, st);
     }
     return launch_emit<DT, KS, 1>(m, queries, Q, thr_s, thr_o, cand_cnt, cand_s, cand_o, row_limit, st);
