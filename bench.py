@@ -303,7 +303,7 @@ def main():
         dom_flops = sum(flops[c] for c in kern_cats[dom])          # algorithmic FLOPs of those launches per step
         achieved = dom_flops * nsteps_prof / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         traffic = None   # HBM/fabric bytes per launch from separate rocprofv3 --pmc passes (tools/pmc_traffic.py)
-        tpath = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")
         if os.path.exists(tpath) and not os.environ.get("VIDMEM_MICROBATCH"):
             rocname = "void (anonymous namespace)::gemm256p_kernel<0, %d, 0>" % (0 if "STORE16" in dom else 1)
             traffic = json.load(open(tpath))["kernels"].get(rocname, {}).get("traffic_bytes")
@@ -311,7 +311,7 @@ def main():
             "bound": "mfma", "kernel": dom, "achieved": achieved, "peak": MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic,
             "traffic_note": "HBM/fabric bytes per launch = 2*FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc "
-                            "passes of this bench (profiles/r1_pmc_traffic.json); algorithmic_bytes = operands + "
+                            "passes of this bench (profiles/r2_pmc_traffic.json); algorithmic_bytes = operands + "
                             "output once per launch",
             "algorithmic_bytes": sum(abytes[c] for c in kern_cats[dom]) / max(launches / nsteps_prof, 1),
             "avg_launch_ms": ms / max(launches, 1), "launches": launches,
@@ -364,7 +364,7 @@ def main():
                                   "achieved": q16["scan_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                   "frac": q16["scan_GBps"] / HBM_PEAK_GBPS, "traffic": None,
                                   "algorithmic_bytes": bytes_scan}
-        tpath = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")
         if os.path.exists(tpath) and Mk == 1_000_000:
             tk = json.load(open(tpath))["kernels"].get("void (anonymous namespace)::topk_scan_kernel<0, 16, 1>", {})
             out["knn"]["roofline"]["traffic"] = tk.get("traffic_bytes")
