@@ -36,7 +36,7 @@ enum vm_status {
     VM_ERR_UNSUPPORTED = -4, /* shape outside what the kernels are built for                             */
     VM_ERR_NO_DEVICE = -5    /* no gfx950 device visible                                                 */
 };
-enum vm_dtype { VM_F16 = 0, VM_BF16 = 1 };
+enum vm_dtype { VM_F16 = 0, VM_BF16 = 1, VM_F32 = 2 /* vm_cosine_exact operands only */ };
 enum vm_act { VM_ACT_GELU = 0, VM_ACT_QUICK_GELU = 1 };
 enum vm_layout { VM_LAYOUT_CHW = 0, VM_LAYOUT_PATCHES = 1 };
 /* Neo4j's vector.similarity.cosine (retriever_hybrid.py:296) is third-party and unpinned: the score mapping is
@@ -166,7 +166,9 @@ int vm_topk_cosine_exact(vm_memory *mem, const void *queries, int Q, int k, int 
                          void *stream);
 /* All-pairs exact cosine, out [Q, S] fp64: the post-compression filter of
  * src/pipeline/retriever_hybrid.py:494-504 (query vs segment embeddings) and a checker for the scan.
- * rows [S, D] dtype need not live in a vm_memory. */
+ * rows [S, D] dtype need not live in a vm_memory.  dtype VM_F32 takes fp32 operands: an embedder that returns fp32
+ * values (every OpenAI-compatible server does) is then scored on its UN-rounded vectors, as the reference scores them
+ * (:497), so `>= compression_threshold` decisions cannot flip on a 16-bit rounding. */
 int vm_cosine_exact(vm_ctx *ctx, const void *queries, int Q, const void *rows, int64_t S, int D, int dtype,
                     double *out, void *stream);
 /* Merge `parts` per-shard results (each [Q,k], sorted as above, -1 padded) into the global top-k:

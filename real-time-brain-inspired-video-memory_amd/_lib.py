@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libvidmem.so")
 
 VM_OK = 0
 VM_ERR_INVALID, VM_ERR_HIP, VM_ERR_NOMEM, VM_ERR_UNSUPPORTED, VM_ERR_NO_DEVICE = -1, -2, -3, -4, -5
-VM_F16, VM_BF16 = 0, 1
+VM_F16, VM_BF16, VM_F32 = 0, 1, 2
 VM_ACT_GELU, VM_ACT_QUICK_GELU = 0, 1
 VM_LAYOUT_CHW, VM_LAYOUT_PATCHES = 0, 1
 VM_SCORE_RAW, VM_SCORE_UNIT_INTERVAL = 0, 1

@@ -52,6 +52,26 @@ __global__ void __launch_bounds__(256)
     out[(size_t)q * out_stride + o] = (qn == 0.0 || mn == 0.0) ? 0.0 : __ddiv_rn(dot, __dmul_rn(qn, mn));
 }
 
+// fp32 operands (vm_cosine_exact, VM_F32): same arithmetic on the values as they are - every fp32 is exact in fp64.
+// grid (ceil(n/256), Q); S is small here (the segments of a handful of hits), so the query stays in global memory.
+__global__ void __launch_bounds__(256)
+    cosine_exact_f32_kernel(const float *__restrict__ queries, const float *__restrict__ rows, int64_t n, int D,
+                            double *__restrict__ out) {
+    const int q = blockIdx.y;
+    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= n) return;
+    const float *qv = queries + (size_t)q * D, *mv = rows + (size_t)o * D;
+    double dot = 0.0, na = 0.0, nb = 0.0;
+    for (int i = 0; i < D; ++i) {
+        const double x = (double)qv[i], y = (double)mv[i];
+        dot = __dadd_rn(dot, __dmul_rn(x, y));
+        na = __dadd_rn(na, __dmul_rn(x, x));
+        nb = __dadd_rn(nb, __dmul_rn(y, y));
+    }
+    const double qn = __dsqrt_rn(na), mn = __dsqrt_rn(nb);
+    out[(size_t)q * n + o] = (qn == 0.0 || mn == 0.0) ? 0.0 : __ddiv_rn(dot, __dmul_rn(qn, mn));
+}
+
 // One block per query: k rounds, each finds the best key strictly after the previous winner in
 // (score desc, index asc) order.  Stateless, so any n works.
 __global__ void __launch_bounds__(256)
@@ -321,10 +341,16 @@ extern "C" int vm_cosine_exact(vm_ctx *ctx, const void *queries, int Q, const vo
                                int dtype, double *out, void *stream) {
     if (!ctx || !queries || !out || Q <= 0 || S < 0 || (S > 0 && !rows))
         return vm_fail(ctx, VM_ERR_INVALID, "vm_cosine_exact: bad arguments");
-    if (D <= 0 || D % 8 != 0) return vm_fail(ctx, VM_ERR_UNSUPPORTED, "vm_cosine_exact: D=%d not a multiple of 8", D);
     if (S == 0) return VM_OK;
     dim3 grid((unsigned)((S + 255) / 256), Q);
     hipStream_t st = (hipStream_t)stream;
+    if (dtype == VM_F32) {
+        if (D <= 0) return vm_fail(ctx, VM_ERR_INVALID, "vm_cosine_exact: D=%d", D);
+        cosine_exact_f32_kernel<<<grid, 256, 0, st>>>((const float *)queries, (const float *)rows, S, D, out);
+        VM_LAUNCH_CHECK(ctx);
+        return VM_OK;
+    }
+    if (D <= 0 || D % 8 != 0) return vm_fail(ctx, VM_ERR_UNSUPPORTED, "vm_cosine_exact: D=%d not a multiple of 8", D);
     if (dtype == VM_F16)
         cosine_exact_kernel<VM_F16><<<grid, 256, (size_t)D * 2, st>>>((const uint16_t *)queries,
                                                                      (const uint16_t *)rows, S, 0, S, D, out, S);

@@ -192,15 +192,30 @@ class EmbeddingMemory:
     def reset_uncertified(self) -> None:
         self._scratch.uncert.zero_()
 
-    def cosine_exact(self, queries, rows) -> torch.Tensor:
-        """All-pairs reference cosine [Q,S] float64 between two row sets (neither needs to be stored)."""
-        q = self._as_rows(queries)
-        r = self._as_rows(rows)
+    def cosine_exact(self, queries, rows, as_f32: bool = False) -> torch.Tensor:
+        """All-pairs reference cosine [Q,S] float64 between two row sets (neither needs to be stored).
+        ``as_f32``: score the vectors as fp32 values instead of rounding them to the memory's 16-bit type first - what
+        the post-compression filter uses, because its operands are fresh embedder outputs that never enter the
+        memory and the reference compares the un-rounded floats with the threshold (retriever_hybrid.py:497-499)."""
+        if as_f32:
+            def f32(x):
+                t = x if isinstance(x, torch.Tensor) else torch.tensor(x, dtype=torch.float32)
+                if t.dim() == 1:
+                    t = t.unsqueeze(0)
+                return t.to(device=self.device, dtype=torch.float32).contiguous()
+            q, r = f32(queries), f32(rows)
+            if q.shape[-1] != r.shape[-1]:
+                raise ValueError(f"embedding dimensions differ: {q.shape[-1]} vs {r.shape[-1]}")
+            dim, dt = q.shape[-1], _lib.VM_F32
+        else:
+            q, r = self._as_rows(queries), self._as_rows(rows)
+            dim, dt = self.dim, _lib.DTYPES[self.dtype_name]
         out = torch.empty((q.shape[0], r.shape[0]), dtype=torch.float64, device=self.device)
         self.ctx.check(self.L.vm_cosine_exact(self.ctx.handle, C.c_void_p(q.data_ptr()), q.shape[0],
-                                              C.c_void_p(r.data_ptr()), r.shape[0], self.dim,
-                                              _lib.DTYPES[self.dtype_name], C.c_void_p(out.data_ptr()),
-                                              _lib.current_stream_ptr()))
+                                              C.c_void_p(r.data_ptr()), r.shape[0], dim, dt,
+                                              C.c_void_p(out.data_ptr()), _lib.current_stream_ptr()))
+        q.record_stream(torch.cuda.current_stream())
+        r.record_stream(torch.cuda.current_stream())
         return out
 
     # ---- persistence (SURVEY.md §8f-1): the reference's only durable store is the `embedding` list property

@@ -162,8 +162,15 @@ class HipVectorSearch:
             if not seg_emb:
                 return []
             # ONE [1, D] x [S, D] exact-cosine launch for all segments of all hits (the reference scores them one
-            # by one in Python, :497); filter >= threshold in encounter order, then [:top_k] (:499-510)
-            sims = self.memory.cosine_exact([query_embedding], seg_emb)[0].cpu().tolist()
+            # by one in Python, :497); filter >= threshold in encounter order, then [:top_k] (:499-510).  The operands
+            # are scored as fp32 values, not rounded to the memory's 16-bit type: they never enter the memory, and a
+            # threshold decision must not flip on a rounding the reference does not make.  A segment whose length differs
+            # from the query's is dropped (the reference's zip-truncating cosine, :655-664, has no defined meaning there).
+            keep = [i for i, e in zip(keep, seg_emb) if len(e) == len(query_embedding)]
+            seg_emb = [e for e in seg_emb if len(e) == len(query_embedding)]
+            if not seg_emb:
+                return []
+            sims = self.memory.cosine_exact([query_embedding], seg_emb, as_f32=True)[0].cpu().tolist()
             kept = [{**owners[i], "content": segments[i], "compression_score": float(sim)}
                     for i, sim in zip(keep, sims) if sim >= self.config.compression_threshold]
             return kept[: self.config.top_k]
