@@ -33,10 +33,38 @@ __device__ __forceinline__ float wave_sum(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
-template <int DT>
+// Streaming (non-temporal) forms for rows that are touched once per pass and are far larger than L2 together.
+typedef float f32x4_v __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_v __attribute__((ext_vector_type(2)));
+template <bool NT>
+__device__ __forceinline__ float4 ld_f4(const float4 *p) {
+    if (NT) {
+        const f32x4_v v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_v *>(p));
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+    return *p;
+}
+template <bool NT>
+__device__ __forceinline__ void st_f4(float4 *p, float4 v) {
+    if (NT) __builtin_nontemporal_store(f32x4_v{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4_v *>(p));
+    else *p = v;
+}
+template <bool NT>
+__device__ __forceinline__ void st_u2(uint2 *p, uint2 v) {
+    if (NT) __builtin_nontemporal_store(u32x2_v{v.x, v.y}, reinterpret_cast<u32x2_v *>(p));
+    else *p = v;
+}
+
+template <int DT, bool NT = false>
 __device__ __forceinline__ float4 load4_16(const uint16_t *p) {
     using E = vm_elem<DT>;
-    const uint2 v = *reinterpret_cast<const uint2 *>(p);
+    uint2 v;
+    if (NT) {
+        const u32x2_v t = __builtin_nontemporal_load(reinterpret_cast<const u32x2_v *>(p));
+        v = make_uint2(t.x, t.y);
+    } else {
+        v = *reinterpret_cast<const uint2 *>(p);
+    }
     const uint16_t *e = reinterpret_cast<const uint16_t *>(&v);
     return make_float4(E::to_float(e[0]), E::to_float(e[1]), E::to_float(e[2]), E::to_float(e[3]));
 }
@@ -52,7 +80,7 @@ __device__ __forceinline__ float4 load4_16(const uint16_t *p) {
 //   out16[row] = LN(x_new) * gamma + beta  (the next GEMM's A operand)
 // Two-pass statistics in registers (mean, then mean of squared deviations), as the oracle computes them.
 // The GEMMs therefore never read the residual: their epilogues are pure 16-bit stores.
-template <int DT, int VPL, int RPW>  // RPW rows per wave: all loads of both rows are in flight before the first use
+template <int DT, int VPL, int RPW, bool NT>  // RPW rows per wave: all loads of both rows are in flight before the first use
 __global__ void __launch_bounds__(256) resid_layernorm_kernel(float *__restrict__ x32,
                                                               const uint16_t *__restrict__ delta16,
                                                               const uint16_t *__restrict__ deltaB16, int write_x,
@@ -71,16 +99,16 @@ __global__ void __launch_bounds__(256) resid_layernorm_kernel(float *__restrict_
         const int row = row0 + r < rows ? row0 + r : rows - 1;
         const float4 *xr = reinterpret_cast<const float4 *>(x32 + (size_t)row * H);
 #pragma unroll
-        for (int i = 0; i < VPL; ++i) v[r][i] = xr[lane + 64 * i];
+        for (int i = 0; i < VPL; ++i) v[r][i] = ld_f4<NT>(xr + lane + 64 * i);
         if (delta16) {
             const uint16_t *dr = delta16 + (size_t)row * H;
 #pragma unroll
-            for (int i = 0; i < VPL; ++i) d[r][i] = load4_16<VM_F16>(dr + 4 * (lane + 64 * i));  // EPI_DELTA16: always fp16
+            for (int i = 0; i < VPL; ++i) d[r][i] = load4_16<VM_F16, NT>(dr + 4 * (lane + 64 * i));  // EPI_DELTA16: always fp16
         }
         if (deltaB16) {
             const uint16_t *er = deltaB16 + (size_t)row * H;
 #pragma unroll
-            for (int i = 0; i < VPL; ++i) e[r][i] = load4_16<VM_F16>(er + 4 * (lane + 64 * i));
+            for (int i = 0; i < VPL; ++i) e[r][i] = load4_16<VM_F16, NT>(er + 4 * (lane + 64 * i));
         }
     }
     float4 g4[VPL], b4[VPL];
@@ -114,7 +142,7 @@ __global__ void __launch_bounds__(256) resid_layernorm_kernel(float *__restrict_
         if (write_x) {
             float4 *xr = reinterpret_cast<float4 *>(x32 + (size_t)row * H);
 #pragma unroll
-            for (int i = 0; i < VPL; ++i) xr[lane + 64 * i] = v[r][i];
+            for (int i = 0; i < VPL; ++i) st_f4<NT>(xr + lane + 64 * i, v[r][i]);
         }
         float sum = 0.f;
 #pragma unroll
@@ -135,7 +163,7 @@ __global__ void __launch_bounds__(256) resid_layernorm_kernel(float *__restrict_
                              E::from_float((v[r][i].w - mean) * rstd * g4[i].w + b4[i].w)};
             uint2 pk;
             __builtin_memcpy(&pk, o, 8);
-            reinterpret_cast<uint2 *>(out16 + (size_t)row * H)[lane + 64 * i] = pk;
+            st_u2<NT>(reinterpret_cast<uint2 *>(out16 + (size_t)row * H) + lane + 64 * i, pk);
         }
     }
 }
@@ -269,15 +297,26 @@ int vm_resid_layernorm(vm_ctx *ctx, int dtype, float *x32, const uint16_t *delta
     const int blocks = (rows + 4 * RPW - 1) / (4 * RPW);
     if (H % 256 != 0) return vm_fail(ctx, VM_ERR_UNSUPPORTED, "row width %d", H);
     vm_prof_scope prof(ctx, VM_PROF_LAYERNORM, st);
-#define RLN16(V) resid_layernorm_kernel<VM_F16, V, RPW><<<blocks, 256, 0, st>>>(x32, delta16, deltaB16, write_x, gamma, beta, eps, out16, rows, H)
-#define RLNB16(V) resid_layernorm_kernel<VM_BF16, V, RPW><<<blocks, 256, 0, st>>>(x32, delta16, deltaB16, write_x, gamma, beta, eps, out16, rows, H)
+    // rows that together exceed the 32 MiB of L2 several times over stream through with the non-temporal policy
+    static int nt_env = -1;
+    if (nt_env < 0) {
+        const char *e = getenv("VIDMEM_LN_NT");
+        nt_env = e ? atoi(e) : 1;
+    }
+    const bool nt = nt_env && (size_t)rows * H * 4 > ((size_t)64 << 20);
+#define RLN16(V) resid_layernorm_kernel<VM_F16, V, RPW, false><<<blocks, 256, 0, st>>>(x32, delta16, deltaB16, write_x, gamma, beta, eps, out16, rows, H)
+#define RLNB16(V) resid_layernorm_kernel<VM_BF16, V, RPW, false><<<blocks, 256, 0, st>>>(x32, delta16, deltaB16, write_x, gamma, beta, eps, out16, rows, H)
+#define RLN16N(V) resid_layernorm_kernel<VM_F16, V, RPW, true><<<blocks, 256, 0, st>>>(x32, delta16, deltaB16, write_x, gamma, beta, eps, out16, rows, H)
+#define RLNB16N(V) resid_layernorm_kernel<VM_BF16, V, RPW, true><<<blocks, 256, 0, st>>>(x32, delta16, deltaB16, write_x, gamma, beta, eps, out16, rows, H)
     if (dtype == VM_F16) {
-        VM_VPL_SWITCH(H, RLN16)
+        if (nt) { VM_VPL_SWITCH(H, RLN16N) } else { VM_VPL_SWITCH(H, RLN16) }
     } else {
-        VM_VPL_SWITCH(H, RLNB16)
+        if (nt) { VM_VPL_SWITCH(H, RLNB16N) } else { VM_VPL_SWITCH(H, RLNB16) }
     }
 #undef RLN16
 #undef RLNB16
+#undef RLN16N
+#undef RLNB16N
     VM_LAUNCH_CHECK(ctx);
     return VM_OK;
 }

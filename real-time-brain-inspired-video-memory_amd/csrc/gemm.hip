@@ -61,6 +61,23 @@ __device__ __forceinline__ size_t out16_index(const GemmArgs &g, int t, int f) {
     return g.head_major ? ((((size_t)(f >> 6) * g.M + t) << 6) | (f & 63)) : (size_t)t * g.ldo + f;
 }
 
+// 16-bit outputs leave with the non-temporal (streaming) policy: a GEMM writes 130-530 MB that the next kernel reads
+// long after the 32 MiB of L2 have turned over, and written with the default policy the 33 MB burst of one round of
+// tiles evicts the weight and activation panels the other CUs are still re-reading (measured on the 86,877-token
+// GEMMs, alternating order: QKV -12..14 %, FC1+GELU -4..7 %, projection -2..3 %, FC2 0..-2 %).
+// Outputs that fit L2 (GemmArgs::stream_out == 0: a streaming session's few frames) keep the default policy, the next
+// kernel finds them there.
+typedef unsigned u32x4_nt __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_nt __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_out16(const GemmArgs &g, uint16_t *p, uint4 v) {
+    if (g.stream_out) __builtin_nontemporal_store(u32x4_nt{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4_nt *>(p));
+    else *reinterpret_cast<uint4 *>(p) = v;
+}
+__device__ __forceinline__ void store_out16(const GemmArgs &g, uint16_t *p, uint2 v) {
+    if (g.stream_out) __builtin_nontemporal_store(u32x2_nt{v.x, v.y}, reinterpret_cast<u32x2_nt *>(p));
+    else *reinterpret_cast<uint2 *>(p) = v;
+}
+
 // XCD-aware renumbering (bijective for any grid size): ids that share (blockIdx % 8) become neighbours.
 __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
     const int xcd = orig & 7, qd = nwg >> 3, rm = nwg & 7;
@@ -90,8 +107,8 @@ __device__ __forceinline__ void epilogue_row(const GemmArgs &g, const f32x4 (&a)
                 v01 = f32x2{quick_gelu(v01.x), quick_gelu(v01.y)};
                 v23 = f32x2{quick_gelu(v23.x), quick_gelu(v23.y)};
             }
-            *reinterpret_cast<uint2 *>(g.out16 + out16_index(g, t, fbase + 16 * i)) =
-                make_uint2(E::pack2(v01.x, v01.y), E::pack2(v23.x, v23.y));
+            store_out16(g, g.out16 + out16_index(g, t, fbase + 16 * i),
+                        make_uint2(E::pack2(v01.x, v01.y), E::pack2(v23.x, v23.y)));
         }
     } else if (EPI == EPI_RESID32) {
         float *orow = g.out32 + (size_t)t * g.ldo + fbase;
@@ -115,6 +132,95 @@ __device__ __forceinline__ void epilogue_row(const GemmArgs &g, const f32x4 (&a)
             *reinterpret_cast<float4 *>(orow + 16 * i) =
                 make_float4((a[i][0] + b4[i].x) + r[i].x, (a[i][1] + b4[i].y) + r[i].y, (a[i][2] + b4[i].z) + r[i].z,
                             (a[i][3] + b4[i].w) + r[i].w);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 16-bit epilogue of the persistent kernel: bias (+ activation), pack, wave-private LDS transpose, stores of
+// 4 token rows x 256 contiguous bytes.  acc[i][p][e] = out[token tbase + 16 p + r16][feature fw + 16 i + 4 h + e].
+//
+// Its LDS traffic (bias table, transpose scratch) is issued by INLINE ASM.  Written as plain C++ accesses, hipcc
+// puts an s_waitcnt vmcnt(0) in front of the first of them: with LDS-DMA in flight it cannot prove that the access
+// does not alias a DMA destination, so every tile's epilogue began by draining the staging of the NEXT tile's first
+// K-tiles - a full memory latency with the matrix pipe idle, once per tile.  (The fragment reads of the K loops do
+// not get that wait)  The asm reads carry no dependency the compiler can see, hence the explicit
+// s_waitcnt lgkmcnt with the destination registers as "+v" operands before each first use.
+// ---------------------------------------------------------------------------------------------------------------
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+template <int OFF>
+__device__ __forceinline__ void lds_rd128(u32x4 &d, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void lds_wr64(unsigned addr, u32x2 v) {
+    asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ unsigned lds_offset(const void *p) {  // byte offset of a __shared__ address inside LDS
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const char *)p;
+}
+
+template <int DT, int EPI, int NP, bool NOSTORE = false>
+__device__ __forceinline__ void epilogue16(const GemmArgs &g, const f32x4 (&acc)[8][NP], const float *bias_lds,
+                                           const char *scratch, int tbase, int fw, int lane) {
+    using EO = vm_elem<(EPI == EPI_DELTA16) ? VM_F16 : DT>;  // output element type
+    const int r16 = lane & 15, h = lane >> 4;
+    const unsigned b_off = lds_offset(bias_lds + fw + 4 * h);
+    const unsigned s_off = lds_offset(scratch);
+    u32x4 braw[8];
+    lds_rd128<0>(braw[0], b_off);
+    lds_rd128<64>(braw[1], b_off);
+    lds_rd128<128>(braw[2], b_off);
+    lds_rd128<192>(braw[3], b_off);
+    lds_rd128<256>(braw[4], b_off);
+    lds_rd128<320>(braw[5], b_off);
+    lds_rd128<384>(braw[6], b_off);
+    lds_rd128<448>(braw[7], b_off);
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(braw[0]), "+v"(braw[1]), "+v"(braw[2]), "+v"(braw[3]), "+v"(braw[4]), "+v"(braw[5]),
+                   "+v"(braw[6]), "+v"(braw[7]));
+    const int wrow = r16 & 7, wsw = wrow << 4;
+    const unsigned w_off = s_off + wrow * 256;
+    const int row0 = lane >> 4, ch = lane & 15;   // transposed read: rows row0 and row0 + 4 of the 8-row pass
+    const unsigned r_off0 = s_off + row0 * 256 + ((ch ^ row0) << 4);
+    const unsigned r_off1 = s_off + (row0 + 4) * 256 + ((ch ^ (row0 + 4)) << 4);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        u32x2 pk[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const f32x4 a = acc[i][p];
+            const f32x4 b = __builtin_bit_cast(f32x4, braw[i]);
+            f32x2 v01 = f32x2{a[0], a[1]} + f32x2{b[0], b[1]};  // v_pk_add_f32
+            f32x2 v23 = f32x2{a[2], a[3]} + f32x2{b[2], b[3]};
+            if (EPI == EPI_GELU16) {
+                v01 = gelu_erf2(v01);
+                v23 = gelu_erf2(v23);
+            }
+            if (EPI == EPI_QGELU16) {
+                v01 = f32x2{quick_gelu(v01.x), quick_gelu(v01.y)};
+                v23 = f32x2{quick_gelu(v23.x), quick_gelu(v23.y)};
+            }
+            pk[i] = u32x2{EO::pack2(v01.x, v01.y), EO::pack2(v23.x, v23.y)};  // v_cvt_pk_*
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if ((r16 >> 3) == half) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) lds_wr64(w_off + ((32 * i + 8 * h) ^ wsw), pk[i]);
+            }
+            u32x4 v0, v1;
+            lds_rd128<0>(v0, r_off0);
+            lds_rd128<0>(v1, r_off1);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v0), "+v"(v1));
+            const int t = tbase + 16 * p + 8 * half + row0;
+            if (NOSTORE) {
+                asm volatile("" ::"v"(v0), "v"(v1));
+            } else {
+                if (t < g.M) store_out16(g, g.out16 + out16_index(g, t, fw + ch * 8), make_uint4(v0.x, v0.y, v0.z, v0.w));
+                if (t + 4 < g.M)
+                    store_out16(g, g.out16 + out16_index(g, t + 4, fw + ch * 8), make_uint4(v1.x, v1.y, v1.z, v1.w));
+            }
+        }
     }
 }
 
@@ -364,8 +470,8 @@ __global__ void __launch_bounds__(512, 1) gemm256p_kernel(GemmArgs g) {
     const unsigned w64 = (unsigned)(64 * K * 2), x32 = (unsigned)(32 * g.ldx * 2);   // region *1 = region *0 + 64 / 32 rows
     auto set_sources = [&](int tile) {
         const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-        so_w = (unsigned)((tn << 8) * K * 2);
-        so_x = (unsigned)(((size_t)(tm << 8) * g.ldx) * 2);
+        so_w = (ABL & 64) ? 0u : (unsigned)((tn << 8) * K * 2);                      // ablation: every tile reads W tile 0
+        so_x = (ABL & 32) ? 0u : (unsigned)(((size_t)(tm << 8) * g.ldx) * 2);        // ablation: ... token panel 0
     };
     auto dma2 = [&](const __amdgpu_buffer_rsrc_t rs, const unsigned (&voff)[2], unsigned soff, const int (&dst)[2],
                     int extra, int buf) {
@@ -432,6 +538,13 @@ __global__ void __launch_bounds__(512, 1) gemm256p_kernel(GemmArgs g) {
     // (a load there would queue behind the LDS-DMA in flight and expose its full latency once per tile)
     float *bias_lds = reinterpret_cast<float *>(smem + 8 * HALF_BYTES);
     for (int i = tid; i < g.N; i += 512) bias_lds[i] = g.bias[i];
+    if (ABL & 128) {  // ablation: start the workgroups of an XCD in 4 groups, g.P x 10 ns apart (epilogue bursts desynchronised)
+        const int grp = (blockIdx.x >> 3) & 3;
+        const unsigned long long t_start = __builtin_readcyclecounter();
+        (void)t_start;
+        const unsigned long long r0 = wall_clock64();
+        while (wall_clock64() - r0 < (unsigned long long)(grp * g.P)) __builtin_amdgcn_s_sleep(8);
+    }
     set_sources(tile);
     stage_Wa0(0, 0);
     stage_Xb0(0, 0);
@@ -548,51 +661,9 @@ __global__ void __launch_bounds__(512, 1) gemm256p_kernel(GemmArgs g) {
                     for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
             } else if (OUT16) {
                 // 2 KiB of wave-private scratch each in the spare LDS behind the bias table: 8 token rows per pass
-                char *scratch = smem + 8 * HALF_BYTES + ((g.N * 4 + 15) & ~15) + (wr * 4 + wc) * 2048;
-                const int fw = f0 + wr * 128;
-                float4 b4[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) b4[i] = *reinterpret_cast<const float4 *>(bias_lds + fw + 16 * i + 4 * h);
-                const int wrow = r16 & 7, wsw = wrow << 4;
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    // the column's 16-bit values (bias, activation) once, then two 8-row passes through the scratch
-                    uint2 pk[8];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const f32x4 a = acc[i][p];
-                        f32x2 v01 = f32x2{a[0], a[1]} + f32x2{b4[i].x, b4[i].y};  // v_pk_add_f32
-                        f32x2 v23 = f32x2{a[2], a[3]} + f32x2{b4[i].z, b4[i].w};
-                        if (EPI == EPI_GELU16) {
-                            v01 = gelu_erf2(v01);
-                            v23 = gelu_erf2(v23);
-                        }
-                        if (EPI == EPI_QGELU16) {
-                            v01 = f32x2{quick_gelu(v01.x), quick_gelu(v01.y)};
-                            v23 = f32x2{quick_gelu(v23.x), quick_gelu(v23.y)};
-                        }
-                        pk[i] = make_uint2(EO::pack2(v01.x, v01.y), EO::pack2(v23.x, v23.y));  // v_cvt_pk_*
-                    }
-#pragma unroll
-                    for (int half = 0; half < 2; ++half) {
-                        if ((r16 >> 3) == half) {
-#pragma unroll
-                            for (int i = 0; i < 8; ++i)
-                                *reinterpret_cast<uint2 *>(scratch + wrow * 256 + ((32 * i + 8 * h) ^ wsw)) = pk[i];
-                        }
-#pragma unroll
-                        for (int it = 0; it < 2; ++it) {
-                            const int c = it * 64 + lane, row = c >> 4, ch = c & 15;
-                            const uint4 v = *reinterpret_cast<const uint4 *>(scratch + row * 256 + ((ch ^ row) << 4));
-                            const int t = t0 + wc * 64 + 16 * p + 8 * half + row;
-                            if (ABL & 8) {
-                                asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
-                            } else if (t < M) {
-                                *reinterpret_cast<uint4 *>(g.out16 + out16_index(g, t, fw + ch * 8)) = v;
-                            }
-                        }
-                    }
-                }
+                const char *scratch = smem + 8 * HALF_BYTES + ((g.N * 4 + 15) & ~15) + (wr * 4 + wc) * 2048;
+                if (ABL & 8) epilogue16<DT, EPI, 4, true>(g, acc, bias_lds, scratch, t0 + wc * 64, f0 + wr * 128, lane);
+                else epilogue16<DT, EPI, 4>(g, acc, bias_lds, scratch, t0 + wc * 64, f0 + wr * 128, lane);
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -724,9 +795,19 @@ int launch_epi(vm_ctx *ctx, const GemmArgs &g, hipStream_t st) {
     // a 256^2 grid must give (nearly) every CU a tile; below that the 128^2 kernel fills the chip better
     const bool use256 = (variant == 2 || variant == 3) ? big_ok : (variant == 1 ? false : (big_ok && tiles256 * 10 >= ctx->num_cus * 8));
 #ifdef VM_GEMM_ABLATE
-    if (variant >= 1024 && DT == VM_F16) {  // persistent-kernel ablations: 1024 + 8 (no stores) / + 16 (no epilogue)
+    if (variant >= 1024 && DT == VM_F16) {  // persistent-kernel ablations: 1024 + ABL bits: 1024 + 8 (no stores) / + 16 (no epilogue)
         const size_t lds = 8 * HALF_BYTES + (size_t)g.N * 4 + 16384;
         const int grid = tiles256 < ctx->num_cus ? tiles256 : ctx->num_cus;
+#define ABLP(A)                                                                                                   \
+    if (variant == 1024 + (A)) {                                                                                  \
+        auto k = gemm256p_kernel<VM_F16, EPI, (A)>;                                                               \
+        (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
+        k<<<grid, 512, lds, st>>>(g);                                                                             \
+        VM_LAUNCH_CHECK(ctx);                                                                                     \
+        return VM_OK;                                                                                             \
+    }
+        ABLP(32) ABLP(64) ABLP(96) ABLP(96 + 16) ABLP(128) ABLP(256)
+#undef ABLP
         if (variant == 1024 + 8) {
             auto k = gemm256p_kernel<VM_F16, EPI, 8>;
             (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -812,5 +893,7 @@ int vm_gemm(vm_ctx *ctx, int dtype, const GemmArgs &g, int epi, hipStream_t st) 
     if (g.M <= 0 || g.N % 128 != 0 || g.K % BK != 0 || g.K <= 0)
         return vm_fail(ctx, VM_ERR_UNSUPPORTED, "gemm shape M=%d N=%d K=%d (need N%%128==0, K%%64==0)", g.M, g.N,
                        g.K);
-    return dtype == VM_F16 ? launch<VM_F16>(ctx, g, epi, st) : launch<VM_BF16>(ctx, g, epi, st);
+    GemmArgs a = g;
+    a.stream_out = (size_t)g.M * g.N * 2 > ((size_t)32 << 20);  // more than the 8 x 4 MiB of L2
+    return dtype == VM_F16 ? launch<VM_F16>(ctx, a, epi, st) : launch<VM_BF16>(ctx, a, epi, st);
 }

@@ -26,6 +26,7 @@ struct GemmArgs {
     int P, T;           // EPI_PATCH only: patches per frame, tokens per frame
     int prof_cat;       // vm_prof_cat of this launch (bench.py's per-kernel breakdown)
     int head_major;     // 16-bit epilogues: out16 is [N/64][M][64] (per-head contiguous blocks) instead of [M, ldo]
+    int stream_out;     // set by vm_gemm: the 16-bit output is larger than L2 and leaves with the non-temporal policy
 };
 
 int vm_gemm(vm_ctx *ctx, int dtype, const GemmArgs &g, int epi, hipStream_t st);
