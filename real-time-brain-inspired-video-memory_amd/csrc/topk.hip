@@ -56,7 +56,8 @@ __global__ void __launch_bounds__(SCAN_THREADS)
     topk_scan_kernel(const uint16_t *__restrict__ mem, const float *__restrict__ rnorm,
                      const uint16_t *__restrict__ queries, const int64_t *__restrict__ d_total, int64_t cap,
                      int ring, int D, int Q, int q_pad, float *__restrict__ part_s, int *__restrict__ part_o,
-                     int64_t row_limit, const float *__restrict__ thr_s, const int *__restrict__ thr_o, int qgroups) {
+                     int64_t row_limit, const float *__restrict__ thr_s, const int *__restrict__ thr_o, int qgroups,
+                     int nt_flag) {
     using E = vm_elem<DT>;
     using vec8 = typename E::vec8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -130,9 +131,21 @@ __global__ void __launch_bounds__(SCAN_THREADS)
         if (row > rv.n - 1) row = rv.n - 1;  // tail lanes re-read the last row; their scores are masked below
         return reinterpret_cast<const uint4 *>(mem + (size_t)row * D) + h;
     };
+    // one query group = every row byte is read once in this launch: non-temporal loads (VIDMEM_TOPK_NT=0: default
+    // policy); with several, the groups of a row block share the rows through their XCD's L2
+    typedef unsigned u32x4_nt __attribute__((ext_vector_type(4)));
+    const bool nt_rows = nt_flag && qgroups == 1;
     auto issue = [&](const uint4 *src, int s0, uint4 (&a)[LB]) {
 #pragma unroll
-        for (int u = 0; u < LB; ++u) a[u] = src[(s0 + u < ksteps ? s0 + u : ksteps - 1) * 4];
+        for (int u = 0; u < LB; ++u) {
+            const uint4 *p = src + (s0 + u < ksteps ? s0 + u : ksteps - 1) * 4;
+            if (nt_rows) {
+                const u32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_nt *>(p));
+                a[u] = make_uint4(v.x, v.y, v.z, v.w);
+            } else {
+                a[u] = *p;
+            }
+        }
     };
     // (single-tile scans, QT == 1, run three waves per SIMD and are HBM-bound at 5.5 TB/s without it; there the extra
     // registers and copies cost 15 %, so they keep the plain load-then-use order)
@@ -717,9 +730,16 @@ int launch_scan(vm_memory *m, const ScanPlan &p, int nblk, int64_t row_limit, co
         if (e != hipSuccess) return vm_fail(m->ctx, VM_ERR_HIP, "LDS opt-in %zu: %s", p.lds, hipGetErrorString(e));
     }
     const dim3 grid = p.qgroups > 1 ? dim3(nblk * p.qgroups) : dim3(nblk);
+    static int nt_env = -1;
+    if (nt_env < 0) {
+        const char *e = getenv("VIDMEM_TOPK_NT");
+        nt_env = e ? atoi(e) : 1;
+    }
+    const int nt_flag = nt_env && row_limit >= m->cap;  // full passes only: the sampling pre-pass's rows are read again
     vm_prof_scope prof(m->ctx, VM_PROF_TOPK_SCAN, st);
     kern<<<grid, SCAN_THREADS, p.lds, st>>>(m->rows, m->rnorm32, (const uint16_t *)queries, m->d_total, m->cap,
-                                          m->ring, m->D, Q, p.q_pad, part_s, part_o, row_limit, thr_s, thr_o, p.qgroups);
+                                          m->ring, m->D, Q, p.q_pad, part_s, part_o, row_limit, thr_s, thr_o, p.qgroups,
+                                          nt_flag);
     VM_LAUNCH_CHECK(m->ctx);
     return VM_OK;
 }

@@ -65,12 +65,13 @@ __device__ __forceinline__ void lds_write_b32(unsigned addr, unsigned v) {
 // NG = 16-query groups per wave: 1 (<= 128 queries per superblock: HBM-bound) or 2 (<= 256: every A fragment read from
 // LDS feeds two MFMAs; with one group per wave the eight waves' A reads - 384 KB per tile - saturate the LDS).
 // thr_s == null: no cut, every score is emitted (the first pass of the cut cascade, over a few hundred rows).
-template <int DT, int KS, int NG>
+template <int DT, int KS, int NG, bool DEEP>
 __global__ void __launch_bounds__(EM_THREADS, 1)
     topk_emit_kernel(const uint16_t *__restrict__ mem, const float *__restrict__ rnorm,
                      const uint16_t *__restrict__ queries, const int64_t *__restrict__ d_total, int64_t cap, int ring,
                      int Q, const float *__restrict__ thr_s, const int *__restrict__ thr_o, int *__restrict__ cand_cnt,
-                     float *__restrict__ cand_s, int *__restrict__ cand_o, int nsuper, int64_t row_limit) {
+                     float *__restrict__ cand_s, int *__restrict__ cand_o, int nsuper, int64_t row_limit,
+                     int nt_rows) {
     using E = vm_elem<DT>;
     using vec8 = typename E::vec8;
     constexpr int D = 128 * KS;
@@ -152,8 +153,14 @@ __global__ void __launch_bounds__(EM_THREADS, 1)
         const int off = p * 1024 + ln * 16;
         const int row = off / ROW_BYTES, cp = (off - row * ROW_BYTES) >> 4;
         const int c = cp ^ (row & 15);
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(mem + ((size_t)tile * EM_ROWS + row) * D + c * 8),
-                                         (lds_ptr_t)(stage0 + buf * STAGE_BYTES + p * 1024), 16, 0, 0);
+        // one superblock = every row byte is read exactly once in this launch: non-temporal (aux 2); with several, the
+        // superblocks of a row block share the tile through their XCD's L2 and keep the default policy
+        if (nt_rows)
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(mem + ((size_t)tile * EM_ROWS + row) * D + c * 8),
+                                             (lds_ptr_t)(stage0 + buf * STAGE_BYTES + p * 1024), 16, 0, 2);
+        else
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(mem + ((size_t)tile * EM_ROWS + row) * D + c * 8),
+                                             (lds_ptr_t)(stage0 + buf * STAGE_BYTES + p * 1024), 16, 0, 0);
     };
     auto stage_norm = [&](int64_t tile, int buf) {  // last wave only: 64 reciprocal norms (this tile's 32 + 32 more)
         int64_t ri = tile * EM_ROWS + lane;
@@ -189,33 +196,56 @@ __global__ void __launch_bounds__(EM_THREADS, 1)
         pending = 0;
     };
 
-    // prologue: STAGES - 1 tiles in flight
+    // prologue: DEEP fills every stage, the shallow schedule leaves one free for the tile staged during the first compute
 #pragma unroll
-    for (int s = 0; s < STAGES - 1; ++s)
+    for (int s = 0; s < (DEEP ? STAGES : STAGES - 1); ++s)
         if (s < my_tiles) stage_tile(bx + (int64_t)s * nbx, s);
 
     for (int64_t it = 0; it < my_tiles; ++it) {
         const int64_t tile = bx + it * nbx;
         const int buf = (int)(it % STAGES);
-        // retire this tile's DMA: younger ones are those of the (STAGES - 2) tiles staged after it
-        if (STAGES == 3 && it + 1 < my_tiles) {
-            // exactly the next tile's pieces may stay in flight: PPW per wave, + the norm piece on the last wave
-            if (wave == EM_WAVES - 1) wait_vmcnt<PPW + 1>(); else wait_vmcnt<PPW>();
+        bool do_stage, spread;
+        int64_t ntile;
+        int nbuf;
+        if constexpr (DEEP) {
+            // A workgroup of a bandwidth-bound scan computes ~1 k cycles per tile and waits ~4 k for the next one: what
+            // matters is bytes in flight.  A second barrier right behind the compute frees the tile's stage at once, and
+            // the tile STAGES ahead goes into it before the wait: all STAGES stages are in flight while the CU waits
+            // (the shallow schedule below has STAGES - 1).
+            const int64_t younger = my_tiles - 1 - it < STAGES - 1 ? my_tiles - 1 - it : STAGES - 1;
+            if (younger >= 2) {
+                if (wave == EM_WAVES - 1) wait_vmcnt<2 * PPW + 2>(); else wait_vmcnt<2 * PPW>();
+            } else if (younger == 1) {
+                if (wave == EM_WAVES - 1) wait_vmcnt<PPW + 1>(); else wait_vmcnt<PPW>();
+            } else {
+                wait_vmcnt<0>();
+            }
+            __builtin_amdgcn_s_barrier();  // every wave's pieces of this tile have landed
+            do_stage = false;
+            spread = false;
+            ntile = tile + (int64_t)STAGES * nbx;
+            nbuf = buf;
         } else {
-            wait_vmcnt<0>();
+            // retire this tile's DMA: younger ones are those of the (STAGES - 2) tiles staged after it
+            if (STAGES == 3 && it + 1 < my_tiles) {
+                // exactly the next tile's pieces may stay in flight: PPW per wave, + the norm piece on the last wave
+                if (wave == EM_WAVES - 1) wait_vmcnt<PPW + 1>(); else wait_vmcnt<PPW>();
+            } else {
+                wait_vmcnt<0>();
+            }
+            __builtin_amdgcn_s_barrier();  // every wave's pieces of this tile have landed; everyone is done with tile it-1
+            // LDS-DMA of tile it + STAGES - 1: an idle wave issues its pieces at once; a computing wave spreads them
+            // over its MFMA batches below (an LDS-DMA instruction takes ~100 cycles to issue: issued as one block by
+            // all eight waves right after the barrier, nobody fed the matrix pipe for ~1 k cycles per tile)
+            do_stage = it + STAGES - 1 < my_tiles;
+            ntile = tile + (int64_t)(STAGES - 1) * nbx;
+            nbuf = (int)((it + STAGES - 1) % STAGES);
+            // (spreading them also over the 2 KS batches of an un-paired wave cost 15 %: those waves are LDS-read-bound
+            // and every extra instruction between their MFMA batches shows)
+            spread = paired && active;
+            if (do_stage && !spread) stage_tile(ntile, nbuf);
         }
-        __builtin_amdgcn_s_barrier();  // every wave's pieces of this tile have landed; everyone is done with tile it-1
-        // LDS-DMA of tile it + STAGES - 1: an idle wave issues its pieces at once; a computing wave spreads them over
-        // its MFMA batches below (an LDS-DMA instruction takes ~100 cycles to issue: issued as one block by all
-        // eight waves right after the barrier, nobody fed the matrix pipe for ~1 k cycles per tile)
-        const bool do_stage = it + STAGES - 1 < my_tiles;
-        const int64_t ntile = tile + (int64_t)(STAGES - 1) * nbx;
-        const int nbuf = (int)((it + STAGES - 1) % STAGES);
-        // (spreading them also over the 2 KS batches of an un-paired wave cost 15 %: those waves are LDS-read-bound and
-        // every extra instruction between their MFMA batches shows)
-        const bool spread = paired && active;
-        if (do_stage && !spread) stage_tile(ntile, nbuf);
-        if (!active) continue;
+        if (active) {
         const unsigned tb = lds0 + buf * STAGE_BYTES;  // LDS byte address of this tile's image
         for (int rb = rb0; rb < rb1; ++rb) {
             // A fragment of k-step s = 4 m + t: logical chunk c = 16 m + 4 t + h of row (16 rb + r16), stored at chunk
@@ -345,6 +375,11 @@ __global__ void __launch_bounds__(EM_THREADS, 1)
                 }
             }
         }
+        }  // active
+        if constexpr (DEEP) {
+            __builtin_amdgcn_s_barrier();  // everyone is done reading this stage
+            if (it + STAGES < my_tiles) stage_tile(ntile, nbuf);
+        }
     }
     if (pending) flush();
     if (!thr_s && bx == 0 && active && tid < 64 * EM_WAVES) {  // dense pass: candidate count = rows scanned
@@ -467,13 +502,13 @@ __global__ void __launch_bounds__(CP_THREADS)
     if (tid == 0 && mark) mark[q] = (cnt > VM_EMIT_CAP || too_many) ? 1 : 0;
 }
 
-template <int DT, int KS, int NG>
+template <int DT, int KS, int NG, bool DEEP>
 int launch_emit(vm_memory *m, const void *queries, int Q, const float *thr_s, const int *thr_o, int *cand_cnt,
                 float *cand_s, int *cand_o, int64_t row_limit, hipStream_t st) {
     constexpr int D = 128 * KS;
     constexpr int STAGES = KS <= 6 ? 3 : 2;
     const size_t lds = (size_t)STAGES * (EM_ROWS * 2 * D + 256) + (size_t)EM_WAVES * EM_WBUF * 12;
-    auto kern = topk_emit_kernel<DT, KS, NG>;
+    auto kern = topk_emit_kernel<DT, KS, NG, DEEP>;
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -486,9 +521,15 @@ int launch_emit(vm_memory *m, const void *queries, int Q, const float *thr_s, co
     const int64_t rows = m->cap < row_limit ? m->cap : row_limit;
     const int64_t ntiles = (rows + EM_ROWS - 1) / EM_ROWS;
     if (nbx > ntiles) nbx = (int)ntiles;
+    static int nt_env = -1;
+    if (nt_env < 0) {
+        const char *e = getenv("VIDMEM_TOPK_NT");
+        nt_env = e ? atoi(e) : 1;
+    }
+    const int nt_rows = nt_env && nsuper == 1 && row_limit >= m->cap;  // the full pass of a one-superblock search
     vm_prof_scope prof(m->ctx, VM_PROF_TOPK_SCAN, st);
     kern<<<nbx * nsuper, EM_THREADS, lds, st>>>(m->rows, m->rnorm32, (const uint16_t *)queries, m->d_total, m->cap,
-                                               m->ring, Q, thr_s, thr_o, cand_cnt, cand_s, cand_o, nsuper, row_limit);
+                                               m->ring, Q, thr_s, thr_o, cand_cnt, cand_s, cand_o, nsuper, row_limit, nt_rows);
     VM_LAUNCH_CHECK(m->ctx);
     return VM_OK;
 }
@@ -496,11 +537,24 @@ int launch_emit(vm_memory *m, const void *queries, int Q, const float *thr_s, co
 template <int DT, int KS>
 int launch_emit_ng(vm_memory *m, const void *queries, int Q, const float *thr_s, const int *thr_o, int *cand_cnt,
                    float *cand_s, int *cand_o, int64_t row_limit, hipStream_t st) {
-    if constexpr (KS <= 6) {  // two query groups per wave need 2 x 16 KS registers for the queries alone (192 of 256 at
-        if (Q > EM_QPB)       // D = 768: checked spill-free with -Rpass-analysis=kernel-resource-usage)
-            return launch_emit<DT, KS, 2>(m, queries, Q, thr_s, thr_o, cand_cnt, cand_s, cand_o, row_limit, st);
+    static int deep_env = -1;
+    if (deep_env < 0) {
+        const char *e = getenv("VIDMEM_EMIT_DEEP");
+        // bit 0: one group per wave (<= 128 queries), bit 1: two groups per wave.  Measured on 1 M x 768 (A/B on one box):
+        // 256 queries 0.547 -> 0.528 ms with the deep schedule, 64 queries 0.312 -> 0.327 ms (a bandwidth-bound scan is not
+        // short of bytes in flight; the second barrier only costs)
+        deep_env = e ? atoi(e) : 2;
     }
-    return launch_emit<DT, KS, 1>(m, queries, Q, thr_s, thr_o, cand_cnt, cand_s, cand_o, row_limit, st);
+    if constexpr (KS <= 6) {  // two query groups per wave need 2 x 16 KS registers for the queries alone (192 of 256 at
+        if (Q > EM_QPB) {     // D = 768: checked spill-free with -Rpass-analysis=kernel-resource-usage)
+            if (deep_env & 2)
+                return launch_emit<DT, KS, 2, true>(m, queries, Q, thr_s, thr_o, cand_cnt, cand_s, cand_o, row_limit, st);
+            return launch_emit<DT, KS, 2, false>(m, queries, Q, thr_s, thr_o, cand_cnt, cand_s, cand_o, row_limit, st);
+        }
+    }
+    if (deep_env & 1)
+        return launch_emit<DT, KS, 1, true>(m, queries, Q, thr_s, thr_o, cand_cnt, cand_s, cand_o, row_limit, st);
+    return launch_emit<DT, KS, 1, false>(m, queries, Q, thr_s, thr_o, cand_cnt, cand_s, cand_o, row_limit, st);
 }
 
 }  // namespace
