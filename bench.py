@@ -223,7 +223,7 @@ def main():
 
     # per-kernel breakdown: ONE extra untimed step with every launch bracketed by HIP events (two event records cost
     # ~7 us per launch here, 12 % of the step, so the timed region records only the dominant kernel's events)
-    mb_frames = int(os.environ.get("VIDMEM_MICROBATCH", "0")) or 4 * (256 // (spec["hidden"] // 256)) * 256 // enc.tokens
+    mb_frames = enc.micro_batch(F)          # frames per encoder pass (csrc/encoder.hip, micro_batch_of)
     passes = -(-F // mb_frames)
     per_step_events = passes * (7 * spec["layers"] + 8) + 16
     ctx.profile_enable(per_step_events + 64)
@@ -423,7 +423,7 @@ def main():
         spec3 = specs.CLIP_L14_336
         enc3 = FrameEncoder(spec3, syn.encoder_weights(spec3, seed=42), dtype="bf16", device=local_rank)
         g3 = torch.Generator(device=dev).manual_seed(4321)
-        mb3 = 4 * (256 // (spec3["hidden"] // 256)) * 256 // enc3.tokens      # 113 frames per encoder pass
+        mb3 = enc3.micro_batch(args.c3_frames)                                # 112 frames per encoder pass
         F3 = args.c3_frames // mb3 * mb3                                      # >= 2048 frames per timing
         fr3 = torch.randint(0, 256, (F3, 336, 336, 3), generator=g3, device=dev, dtype=torch.uint8)
         M3, D3, k3 = 1_000_000, 1024, 20

@@ -99,6 +99,9 @@ int vm_encoder_tokens(const vm_encoder *enc);    /* patches + 1                 
 int vm_encoder_patch_k(const vm_encoder *enc);   /* 3*patch*patch rounded up to 64     */
 int vm_encoder_out_dim(const vm_encoder *enc);   /* proj_dim ? proj_dim : hidden       */
 size_t vm_encode_workspace_bytes(const vm_encoder *enc, int B);
+/* Frames vm_encode runs per pass for a call with B frames (it walks B in micro-batches: a whole number of GEMM tile
+ * rounds, and - for sequences that take one attention workgroup per (frame, head) - of attention rounds). */
+int vm_encode_micro_batch(const vm_encoder *enc, int B);
 /* patches: [B, tokens-1, patch_k] dtype (vm_preprocess, PATCHES layout).  out_emb: [B, out_dim] dtype.
  * l2_normalise: divide each embedding by its L2 norm (fp32) before the cast. */
 int vm_encode(vm_encoder *enc, const void *patches, int B, void *out_emb, int l2_normalise, void *workspace,

@@ -24,7 +24,7 @@ DTYPES = {"f16": VM_F16, "bf16": VM_BF16}
 SYMBOLS = [
     "vm_init", "vm_destroy", "vm_last_error", "vm_abi_version", "vm_preprocess",
     "vm_encoder_create", "vm_encoder_destroy", "vm_encoder_tokens", "vm_encoder_patch_k", "vm_encoder_out_dim",
-    "vm_encode_workspace_bytes", "vm_encode",
+    "vm_encode_workspace_bytes", "vm_encode_micro_batch", "vm_encode",
     "vm_memory_create", "vm_memory_destroy", "vm_memory_append", "vm_memory_size", "vm_memory_capacity",
     "vm_memory_dim", "vm_memory_reset", "vm_memory_sync", "vm_memory_rows",
     "vm_topk_workspace_bytes", "vm_topk_cosine", "vm_topk_redo_workspace_bytes", "vm_topk_redo_flagged",
@@ -74,6 +74,7 @@ def lib() -> C.CDLL:
         "vm_encoder_patch_k": (i32, [vp]),
         "vm_encoder_out_dim": (i32, [vp]),
         "vm_encode_workspace_bytes": (sz, [vp, i32]),
+        "vm_encode_micro_batch": (i32, [vp, i32]),
         "vm_encode": (i32, [vp, vp, i32, vp, i32, vp, sz, vp]),
         "vm_memory_create": (i32, [vp, i64, i32, i32, i32, C.POINTER(vp)]),
         "vm_memory_destroy": (None, [vp]),

@@ -504,6 +504,14 @@ static int micro_batch_of(const vm_encoder *e, int B) {
         const int row_tiles = 4 * (e->ctx->num_cus / col_tiles);
         mb = row_tiles * 256 / e->tokens;
         if (mb < 1) mb = 1;
+        // Sequences past 208 tokens run ONE attention workgroup per (frame, head) and CU (attention.hip, long kernel):
+        // mb * heads items in rounds of num_cus.  Give up < 3 % of the batch when that turns a nearly empty last round
+        // into none (CLIP-L/14-336: 113 frames x 16 heads = 7.06 rounds -> 112 frames = 7 rounds; attention -12 %).
+        if (e->tokens > 208) {
+            const int items = mb * e->d.heads, cus = e->ctx->num_cus;
+            const int full = items / cus * cus;
+            if (full > 0 && full % e->d.heads == 0 && (items - full) * 32 < items) mb = full / e->d.heads;
+        }
     }
     return B < mb ? B : mb;
 }
@@ -536,6 +544,8 @@ extern "C" size_t vm_encode_workspace_bytes(const vm_encoder *e, int B) {
     if (!e || B <= 0) return 0;
     return carve(e, micro_batch_of(e, B), nullptr).bytes;
 }
+
+extern "C" int vm_encode_micro_batch(const vm_encoder *e, int B) { return e && B > 0 ? micro_batch_of(e, B) : 0; }
 
 extern "C" int vm_encode(vm_encoder *e, const void *patches, int B, void *out_emb, int l2_normalise,
                          void *workspace, size_t workspace_bytes, void *stream) {

@@ -118,6 +118,10 @@ class FrameEncoder:
     def workspace_bytes(self, B: int) -> int:
         return int(self.L.vm_encode_workspace_bytes(self.handle, int(B)))
 
+    def micro_batch(self, B: int) -> int:
+        """Frames vm_encode runs per pass when called with B frames (csrc/encoder.hip, micro_batch_of)."""
+        return int(self.L.vm_encode_micro_batch(self.handle, int(B)))
+
     def new_workspace(self, B: int) -> torch.Tensor:
         """A workspace for batches of up to B frames that the CALLER owns (streaming sessions: a captured hipGraph
         bakes the address in, so it must not be the encoder's shared, growable one)."""
