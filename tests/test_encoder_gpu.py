@@ -187,7 +187,7 @@ def test_batching_is_invisible(monkeypatch):
 
 @pytest.mark.parametrize("name,dtype,n", [("vit_b16_224", "f16", 500), ("clip_l14_336", "bf16", 120)])
 def test_bench_size_batches_take_the_big_kernels_and_agree(name, dtype, n):
-    """BASELINE-size micro-batches (441 ViT-B frames / 113 CLIP-L frames per pass) run the persistent 256x256 GEMM
+    """BASELINE-size micro-batches (441 ViT-B frames / 112 CLIP-L frames per pass) run the persistent 256x256 GEMM
     (ragged last row panel, head-major QKV stores) and the streaming / two-pass attention kernels, which the few-frame
     tests above never reach.  Size-independent checks: (1) every frame's embedding equals what the same frame gets
     in a 3-frame launch (128x128 GEMM, one attention item per workgroup) BIT FOR BIT - both tilings accumulate each
@@ -197,6 +197,13 @@ def test_bench_size_batches_take_the_big_kernels_and_agree(name, dtype, n):
     w = syn.encoder_weights(spec, seed=21)
     enc = _encoder(spec, w, dtype)
     S = spec["image"]
+    # vm_encode_micro_batch: frames per pass.  Never more than the call brings; for 577-token sequences (one attention
+    # workgroup per (frame, head) and CU) a whole number of rounds of the device's CUs
+    mb = enc.micro_batch(10 ** 6)
+    assert enc.micro_batch(3) == 3 and 3 < mb < n and enc.micro_batch(mb + 7) == mb
+    if enc.tokens > 208:
+        cus = torch.cuda.get_device_properties(0).multi_processor_count
+        assert (mb * spec["heads"]) % cus == 0, (mb, spec["heads"], cus)
     frames = torch.from_numpy(syn.frames_u8(500, n, S, S)).cuda()
     big = enc.embed_frames(frames)
     assert torch.isfinite(big.float()).all()
