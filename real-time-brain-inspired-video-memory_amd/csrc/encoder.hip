@@ -86,7 +86,8 @@ __global__ void __launch_bounds__(256) resid_layernorm_kernel(float *__restrict_
                                                               const uint16_t *__restrict__ deltaB16, int write_x,
                                                               const float *__restrict__ gamma,
                                                               const float *__restrict__ beta, float eps,
-                                                              uint16_t *__restrict__ out16, int rows, int H) {
+                                                              uint16_t *__restrict__ out16, int rows, int H,
+                                                              int rstride) {  // row r lives at row r * rstride of every array
     using E = vm_elem<DT>;
     const int lane = threadIdx.x & 63;
     const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
@@ -97,16 +98,16 @@ __global__ void __launch_bounds__(256) resid_layernorm_kernel(float *__restrict_
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
         const int row = row0 + r < rows ? row0 + r : rows - 1;
-        const float4 *xr = reinterpret_cast<const float4 *>(x32 + (size_t)row * H);
+        const float4 *xr = reinterpret_cast<const float4 *>(x32 + (size_t)row * rstride * H);
 #pragma unroll
         for (int i = 0; i < VPL; ++i) v[r][i] = ld_f4<NT>(xr + lane + 64 * i);
         if (delta16) {
-            const uint16_t *dr = delta16 + (size_t)row * H;
+            const uint16_t *dr = delta16 + (size_t)row * rstride * H;
 #pragma unroll
             for (int i = 0; i < VPL; ++i) d[r][i] = load4_16<VM_F16, NT>(dr + 4 * (lane + 64 * i));  // EPI_DELTA16: always fp16
         }
         if (deltaB16) {
-            const uint16_t *er = deltaB16 + (size_t)row * H;
+            const uint16_t *er = deltaB16 + (size_t)row * rstride * H;
 #pragma unroll
             for (int i = 0; i < VPL; ++i) e[r][i] = load4_16<VM_F16, NT>(er + 4 * (lane + 64 * i));
         }
@@ -140,7 +141,7 @@ __global__ void __launch_bounds__(256) resid_layernorm_kernel(float *__restrict_
             }
         }
         if (write_x) {
-            float4 *xr = reinterpret_cast<float4 *>(x32 + (size_t)row * H);
+            float4 *xr = reinterpret_cast<float4 *>(x32 + (size_t)row * rstride * H);
 #pragma unroll
             for (int i = 0; i < VPL; ++i) st_f4<NT>(xr + lane + 64 * i, v[r][i]);
         }
@@ -163,7 +164,7 @@ __global__ void __launch_bounds__(256) resid_layernorm_kernel(float *__restrict_
                              E::from_float((v[r][i].w - mean) * rstd * g4[i].w + b4[i].w)};
             uint2 pk;
             __builtin_memcpy(&pk, o, 8);
-            st_u2<NT>(reinterpret_cast<uint2 *>(out16 + (size_t)row * H) + lane + 64 * i, pk);
+            st_u2<NT>(reinterpret_cast<uint2 *>(out16 + (size_t)row * rstride * H) + lane + 64 * i, pk);
         }
     }
 }
@@ -292,7 +293,7 @@ __global__ void __launch_bounds__(256) pool_kernel(const float *__restrict__ x, 
 
 int vm_resid_layernorm(vm_ctx *ctx, int dtype, float *x32, const uint16_t *delta16, const uint16_t *deltaB16,
                        int write_x, const float *gamma, const float *beta, float eps, uint16_t *out16, int rows, int H,
-                       hipStream_t st) {
+                       hipStream_t st, int rstride) {
     constexpr int RPW = 2;
     const int blocks = (rows + 4 * RPW - 1) / (4 * RPW);
     if (H % 256 != 0) return vm_fail(ctx, VM_ERR_UNSUPPORTED, "row width %d", H);
@@ -304,10 +305,10 @@ int vm_resid_layernorm(vm_ctx *ctx, int dtype, float *x32, const uint16_t *delta
         nt_env = e ? atoi(e) : 1;
     }
     const bool nt = nt_env && (size_t)rows * H * 4 > ((size_t)64 << 20);
-#define RLN16(V) resid_layernorm_kernel<VM_F16, V, RPW, false><<<blocks, 256, 0, st>>>(x32, delta16, deltaB16, write_x, gamma, beta, eps, out16, rows, H)
-#define RLNB16(V) resid_layernorm_kernel<VM_BF16, V, RPW, false><<<blocks, 256, 0, st>>>(x32, delta16, deltaB16, write_x, gamma, beta, eps, out16, rows, H)
-#define RLN16N(V) resid_layernorm_kernel<VM_F16, V, RPW, true><<<blocks, 256, 0, st>>>(x32, delta16, deltaB16, write_x, gamma, beta, eps, out16, rows, H)
-#define RLNB16N(V) resid_layernorm_kernel<VM_BF16, V, RPW, true><<<blocks, 256, 0, st>>>(x32, delta16, deltaB16, write_x, gamma, beta, eps, out16, rows, H)
+#define RLN16(V) resid_layernorm_kernel<VM_F16, V, RPW, false><<<blocks, 256, 0, st>>>(x32, delta16, deltaB16, write_x, gamma, beta, eps, out16, rows, H, rstride)
+#define RLNB16(V) resid_layernorm_kernel<VM_BF16, V, RPW, false><<<blocks, 256, 0, st>>>(x32, delta16, deltaB16, write_x, gamma, beta, eps, out16, rows, H, rstride)
+#define RLN16N(V) resid_layernorm_kernel<VM_F16, V, RPW, true><<<blocks, 256, 0, st>>>(x32, delta16, deltaB16, write_x, gamma, beta, eps, out16, rows, H, rstride)
+#define RLNB16N(V) resid_layernorm_kernel<VM_BF16, V, RPW, true><<<blocks, 256, 0, st>>>(x32, delta16, deltaB16, write_x, gamma, beta, eps, out16, rows, H, rstride)
     if (dtype == VM_F16) {
         if (nt) { VM_VPL_SWITCH(H, RLN16N) } else { VM_VPL_SWITCH(H, RLN16) }
     } else {
@@ -568,11 +569,17 @@ extern "C" int vm_encode(vm_encoder *e, const void *patches, int B, void *out_em
         const int rows = nb * T;
         GemmArgs g;
         int g_head_major = 0;
+        static int cls_env = -1;
+        if (cls_env < 0) {
+            const char *ev = getenv("VIDMEM_CLS_LAST");
+            cls_env = ev ? atoi(ev) : 1;
+        }
+        const bool cls_only = cls_env != 0;  // VIDMEM_CLS_LAST=0: the last layer's MLP on every row (developer A/B)
         auto gemm16 = [&](const uint16_t *X, int ldx, const uint16_t *W, const float *bias, uint16_t *out, int M, int N,
-                          int K, int epi, int cat) {
+                          int K, int epi, int cat, int ldo = 0) {
             memset(&g, 0, sizeof(g));
             g.X = X; g.W = W; g.bias = bias; g.out16 = out;
-            g.M = M; g.N = N; g.K = K; g.ldx = ldx; g.ldo = N; g.prof_cat = cat; g.head_major = g_head_major;
+            g.M = M; g.N = N; g.K = K; g.ldx = ldx; g.ldo = ldo ? ldo : N; g.prof_cat = cat; g.head_major = g_head_major;
             return vm_gemm(ctx, dt, g, epi, st);
         };
         // patch embedding: [nb*P, patch_k] x [H, patch_k]^T (+bias) -> 16-bit rows; then x32 = rows + pos (+cls) [+pre-LN]
@@ -592,12 +599,26 @@ extern "C" int vm_encode(vm_encoder *e, const void *patches, int B, void *out_em
             g_head_major = 0;
             if (rc != VM_OK) return rc;
             if ((rc = vm_attention(ctx, dt, ws.qkv16, ws.a16, nb, T, d.heads, st)) != VM_OK) return rc;
-            if ((rc = gemm16(ws.a16, H, w.proj_w, w.proj_b, ws.d16, rows, H, H, EPI_DELTA16, VM_PROF_GEMM_RESID)) != VM_OK) return rc;
-            // a16 = LN2(x32 + proj(l)); x32 itself is NOT rewritten here: the next LN1 (or the pool) folds both
-            if ((rc = vm_resid_layernorm(ctx, dt, ws.x32, ws.d16, nullptr, 0, w.ln2_g, w.ln2_b, d.ln_eps, ws.a16, rows,
-                                         H, st)) != VM_OK) return rc;
-            if ((rc = gemm16(ws.a16, H, w.fc1_w, w.fc1_b, ws.mlp16, rows, d.mlp, H, act_epi, VM_PROF_GEMM_ACT)) != VM_OK) return rc;
-            if ((rc = gemm16(ws.mlp16, d.mlp, w.fc2_w, w.fc2_b, ws.e16, rows, H, d.mlp, EPI_DELTA16, VM_PROF_GEMM_RESID)) != VM_OK) return rc;
+            if (l == d.layers - 1 && cls_only) {
+                // LAST layer: the embedding is pooled from the CLS row alone (vm_pool), and behind the attention every
+                // row depends only on itself - so projection, LN2, FC1 and FC2 run on the nb CLS rows, addressed in
+                // place with a row stride of T rows (GEMM ldx / ldo, LN rstride).  The other rows' branch outputs were
+                // never read by anything; the CLS rows get the same values bit for bit (every GEMM tiling accumulates
+                // an output in the same MFMA order).  6.2 % of ViT-B/16's FLOPs, 3.5 % of CLIP-L/14-336's.
+                const int TH = T * H;
+                if ((rc = gemm16(ws.a16, TH, w.proj_w, w.proj_b, ws.d16, nb, H, H, EPI_DELTA16, VM_PROF_GEMM_RESID, TH)) != VM_OK) return rc;
+                if ((rc = vm_resid_layernorm(ctx, dt, ws.x32, ws.d16, nullptr, 0, w.ln2_g, w.ln2_b, d.ln_eps, ws.a16, nb,
+                                             H, st, T)) != VM_OK) return rc;
+                if ((rc = gemm16(ws.a16, TH, w.fc1_w, w.fc1_b, ws.mlp16, nb, d.mlp, H, act_epi, VM_PROF_GEMM_ACT)) != VM_OK) return rc;
+                if ((rc = gemm16(ws.mlp16, d.mlp, w.fc2_w, w.fc2_b, ws.e16, nb, H, d.mlp, EPI_DELTA16, VM_PROF_GEMM_RESID, TH)) != VM_OK) return rc;
+            } else {
+                if ((rc = gemm16(ws.a16, H, w.proj_w, w.proj_b, ws.d16, rows, H, H, EPI_DELTA16, VM_PROF_GEMM_RESID)) != VM_OK) return rc;
+                // a16 = LN2(x32 + proj(l)); x32 itself is NOT rewritten here: the next LN1 (or the pool) folds both
+                if ((rc = vm_resid_layernorm(ctx, dt, ws.x32, ws.d16, nullptr, 0, w.ln2_g, w.ln2_b, d.ln_eps, ws.a16, rows,
+                                             H, st)) != VM_OK) return rc;
+                if ((rc = gemm16(ws.a16, H, w.fc1_w, w.fc1_b, ws.mlp16, rows, d.mlp, H, act_epi, VM_PROF_GEMM_ACT)) != VM_OK) return rc;
+                if ((rc = gemm16(ws.mlp16, d.mlp, w.fc2_w, w.fc2_b, ws.e16, rows, H, d.mlp, EPI_DELTA16, VM_PROF_GEMM_RESID)) != VM_OK) return rc;
+            }
             pend_proj = ws.d16;
             pend_fc2 = ws.e16;
         }

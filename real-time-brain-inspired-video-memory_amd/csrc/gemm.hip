@@ -429,7 +429,6 @@ __global__ void __launch_bounds__(512, 1) gemm256p_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // vector-memory operations an epilogue leaves behind the last LDS-DMA (its stores; loads are consumed before)
     constexpr bool OUT16 = EPI == EPI_STORE16 || EPI == EPI_DELTA16 || EPI == EPI_GELU16 || EPI == EPI_QGELU16;
-    using EO = vm_elem<(EPI == EPI_DELTA16) ? VM_F16 : DT>;  // output element type
     constexpr int EPI_STORES = OUT16 ? 16 : 32;
 
     const int tid = threadIdx.x, lane = tid & 63;

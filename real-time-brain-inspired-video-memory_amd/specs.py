@@ -16,10 +16,16 @@ CLIP_L14_336 = dict(
 )
 SPECS = {"vit_b16_224": VIT_B16_224, "clip_l14_336": CLIP_L14_336}
 
-# algorithmic FLOPs per frame (2 * MACs of the GEMMs and of QK^T / PV)
-def flops_per_frame(spec) -> float:
+# algorithmic FLOPs per frame (2 * MACs of the GEMMs and of QK^T / PV).
+# executed=True: what vm_encode actually runs - the LAST layer's projection and MLP only on the CLS row, the one row the
+# pooled embedding is read from (csrc/encoder.hip): 33.05 instead of 35.13 GFLOP for ViT-B/16-224.
+def flops_per_frame(spec, executed: bool = False) -> float:
     H, L, M, P = spec["hidden"], spec["layers"], spec["mlp"], spec["patch"]
     n = (spec["image"] // P) ** 2 + 1
-    per_layer = 2 * n * H * 3 * H + 2 * n * H * H + 2 * 2 * n * H * M + 2 * 2 * n * n * H
+    qkv_attn = 2 * n * H * 3 * H + 2 * 2 * n * n * H
+    branch = 2 * n * H * H + 2 * 2 * n * H * M          # attention projection + FC1 + FC2 over n rows
     patch = 2 * (n - 1) * (3 * P * P) * H
-    return float(L * per_layer + patch)
+    total = L * (qkv_attn + branch) + patch
+    if executed:
+        total -= branch - branch // n                    # last layer: one row instead of n
+    return float(total)
