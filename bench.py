@@ -288,18 +288,19 @@ def main():
         # the last layer's projection / FC1 / FC2 run on the CLS rows only (one per frame): rows -> frames there
         Lf = spec["layers"] - 1
         flops = {  # algorithmic FLOPs of one step's launches of each GEMM instantiation (2*M*N*K)
-            "gemm_qkv": sum(2.0 * r * 3 * H * H for r in rows) * spec["layers"],
-            "gemm_act": sum(2.0 * r * M * H for r in rows) * Lf + sum(2.0 * b * M * H for b in mbs),
-            "gemm_resid": sum(2.0 * r * H * H + 2.0 * r * H * M for r in rows) * Lf
-                          + sum(2.0 * b * H * H + 2.0 * b * H * M for b in mbs),
+            "gemm_qkv": sum(2.0 * r * 3 * H * H for r in rows) * Lf      # last layer: K, V of every row ...
+                        + sum(2.0 * r * 2 * H * H for r in rows),
+            "gemm_act": sum(2.0 * r * M * H for r in rows) * Lf,
+            "gemm_resid": sum(2.0 * r * H * H + 2.0 * r * H * M for r in rows) * Lf,
+            # ... and Q, projection, FC1, FC2 of the CLS rows (category gemm_cls: the 128 x 128 kernel)
+            "gemm_cls": sum(2.0 * b * H * H * 2 + 2.0 * b * H * M * 2 for b in mbs),
             "gemm_patch": sum(2.0 * b * (T - 1) * (3 * 16 * 16) * H for b in mbs),
         }
         abytes = {  # operands read once + output written once, per step
-            "gemm_qkv": sum(2.0 * (r * H + 3 * H * H + r * 3 * H) for r in rows) * spec["layers"],
-            "gemm_act": sum(2.0 * (r * H + M * H + r * M) for r in rows) * Lf
-                        + sum(2.0 * (b * H + M * H + b * M) for b in mbs),
-            "gemm_resid": sum(2.0 * (r * H + H * H + r * H) + 2.0 * (r * M + H * M + r * H) for r in rows) * Lf
-                          + sum(2.0 * (b * H + H * H + b * H) + 2.0 * (b * M + H * M + b * H) for b in mbs),
+            "gemm_qkv": sum(2.0 * (r * H + 3 * H * H + r * 3 * H) for r in rows) * Lf
+                        + sum(2.0 * (r * H + 2 * H * H + r * 2 * H) for r in rows),
+            "gemm_act": sum(2.0 * (r * H + M * H + r * M) for r in rows) * Lf,
+            "gemm_resid": sum(2.0 * (r * H + H * H + r * H) + 2.0 * (r * M + H * M + r * H) for r in rows) * Lf,
             "gemm_patch": sum(2.0 * (b * (T - 1) * 768 + 768 * H + b * (T - 1) * H) for b in mbs),
         }
         ms = sum(prof[c][0] for c in kern_cats[dom])
@@ -324,7 +325,7 @@ def main():
         }
         out["kernel_time_ms_per_step"] = {c: round(v[0], 4) for c, v in breakdown.items() if v[1]}
         out["kernel_time_note"] = "one untimed step with every launch event-bracketed (adds ~7 us per launch)"
-        enc_ms = sum(breakdown[c][0] for c in ("gemm_patch", "gemm_qkv", "gemm_act", "gemm_resid", "attention",
+        enc_ms = sum(breakdown[c][0] for c in ("gemm_patch", "gemm_qkv", "gemm_act", "gemm_resid", "gemm_cls", "attention",
                                                 "layernorm", "pool"))
         # executed FLOPs (last layer's MLP on the CLS rows only: 33.05 GFLOP per frame, not the 35.13 of every row)
         out["encoder_tflops"] = (specs.flops_per_frame(spec, executed=True) * F / (enc_ms * 1e-3) / 1e12
@@ -465,10 +466,10 @@ def main():
         T3, H3, M3m = enc3.tokens, spec3["hidden"], spec3["mlp"]
         rows3 = mb3 * T3
         passes3 = F3 // mb3
-        # QKV on every row of every layer; projection + FC2 on every row of all layers but the last, on the CLS rows there
-        fl3 = passes3 * (spec3["layers"] * 2.0 * rows3 * 3 * H3 * H3
+        # projection + FC2 (and Q) on every row of all layers but the last, on the CLS rows there
+        fl3 = passes3 * ((spec3["layers"] - 1) * 2.0 * rows3 * 3 * H3 * H3
+                         + 2.0 * rows3 * 2 * H3 * H3          # last layer: K, V of every row (its CLS-row GEMMs: gemm_cls)
                          + (spec3["layers"] - 1) * (2.0 * rows3 * H3 * H3 + 2.0 * rows3 * H3 * M3m)
-                         + (2.0 * mb3 * H3 * H3 + 2.0 * mb3 * H3 * M3m)
                          + 2.0 * mb3 * (T3 - 1) * enc3.patch_k * H3)
         ms3 = sum(p3[c][0] for c in ("gemm_patch", "gemm_qkv", "gemm_resid"))
         n3 = sum(p3[c][1] for c in ("gemm_patch", "gemm_qkv", "gemm_resid"))

@@ -189,7 +189,9 @@ int vm_topk_merge(vm_ctx *ctx, const double *scores, const int64_t *rows, int pa
 enum vm_prof_cat {
     VM_PROF_PREPROCESS = 0, VM_PROF_GEMM_PATCH, VM_PROF_GEMM_QKV, VM_PROF_GEMM_ACT, VM_PROF_GEMM_RESID,
     VM_PROF_ATTENTION, VM_PROF_LAYERNORM, VM_PROF_POOL, VM_PROF_APPEND, VM_PROF_TOPK_SCAN, VM_PROF_TOPK_FINALIZE,
-    VM_PROF_TOPK_EXACT, VM_PROF_TOPK_MERGE, VM_PROF_NCAT
+    VM_PROF_TOPK_EXACT, VM_PROF_TOPK_MERGE,
+    VM_PROF_GEMM_CLS,   /* the last encoder layer's GEMMs over the CLS rows only (one row per frame) */
+    VM_PROF_NCAT
 };
 int vm_profile_enable(vm_ctx *ctx, int max_events);   /* 0 disables and frees the pool */
 int vm_profile_read(vm_ctx *ctx, double *total_ms_host /*[VM_PROF_NCAT]*/, int64_t *launches_host /*[VM_PROF_NCAT]*/);

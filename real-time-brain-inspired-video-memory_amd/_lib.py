@@ -32,7 +32,7 @@ SYMBOLS = [
     "vm_cosine_exact", "vm_topk_merge", "vm_profile_enable", "vm_profile_read", "vm_profile_mask",
 ]
 PROF_CATS = ["preprocess", "gemm_patch", "gemm_qkv", "gemm_act", "gemm_resid", "attention", "layernorm", "pool",
-             "append", "topk_scan", "topk_finalize", "topk_exact", "topk_merge"]
+             "append", "topk_scan", "topk_finalize", "topk_exact", "topk_merge", "gemm_cls"]
 
 
 class VidmemError(RuntimeError):

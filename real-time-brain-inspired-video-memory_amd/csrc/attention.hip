@@ -268,7 +268,8 @@ __device__ __forceinline__ void attend_tile_pass2(const char *kl, const char *vl
 // lands while every wave runs pass 1 of its first query tile; then tiles wave, wave + NW, ...
 template <int DT, int NT, bool EXACT, int NW>
 __global__ void __launch_bounds__(NW * 64, 1)
-    attention_long_kernel(const uint16_t *__restrict__ qkv, uint16_t *__restrict__ ctx_out, int T, int heads) {
+    attention_long_kernel(const uint16_t *__restrict__ qkv, uint16_t *__restrict__ ctx_out, int T, int heads,
+                          int qt_lim) {
     using E = vm_elem<DT>;
     using vec8 = typename E::vec8;
     constexpr int ROWS = NT * 16;
@@ -305,14 +306,15 @@ __global__ void __launch_bounds__(NW * 64, 1)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     stage(2, vl);
-    float mx = attend_rowmax<DT, NT, EXACT>(kl, q0, q1, T, lane);  // needs K only: overlaps the V fill
+    float mx = 0.f;
+    if (wave < qt_lim) mx = attend_rowmax<DT, NT, EXACT>(kl, q0, q1, T, lane);  // needs K only: overlaps the V fill
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int qt = wave; qt < NT; qt += NW) {
+    for (int qt = wave; qt < qt_lim; qt += NW) {
         const int qtok = qt * 16 + r16;
         const bool qvalid = qtok < T;
         const vec8 qa = q0, qb = q1;
-        if (qt + NW < NT) load_q(qt + NW, q0, q1);
+        if (qt + NW < qt_lim) load_q(qt + NW, q0, q1);
         if (qt != wave) mx = attend_rowmax<DT, NT, EXACT>(kl, qa, qb, T, lane);
         attend_tile_pass2<DT, NT, EXACT>(kl, vl, qa, qb, mx, T, lane, qvalid,
                                          ctx_out + ((size_t)b * T + (qvalid ? qtok : 0)) * H + head * 64);
@@ -320,7 +322,7 @@ __global__ void __launch_bounds__(NW * 64, 1)
 }
 
 template <int DT, int NT, bool EXACT>
-int launch_long(vm_ctx *ctx, const uint16_t *qkv, uint16_t *out, int B, int T, int heads, hipStream_t st) {
+int launch_long(vm_ctx *ctx, const uint16_t *qkv, uint16_t *out, int B, int T, int heads, hipStream_t st, int qt_lim) {
     const size_t lds = (size_t)NT * 16 * 128 * 2;
     // 16 waves (4 per SIMD; the kernel needs ~80 VGPRs): 21.1 ms vs 27.0 ms with 8 waves per 256-frame CLIP-L pass
     auto kern = attention_long_kernel<DT, NT, EXACT, 16>;
@@ -330,7 +332,7 @@ int launch_long(vm_ctx *ctx, const uint16_t *qkv, uint16_t *out, int B, int T, i
         attr_set = true;
     }
     vm_prof_scope prof(ctx, VM_PROF_ATTENTION, st);
-    kern<<<B * heads, 1024, lds, st>>>(qkv, out, T, heads);
+    kern<<<B * heads, 1024, lds, st>>>(qkv, out, T, heads, qt_lim < NT ? qt_lim : NT);
     VM_LAUNCH_CHECK(ctx);
     return VM_OK;
 }
@@ -339,7 +341,7 @@ int launch_long(vm_ctx *ctx, const uint16_t *qkv, uint16_t *out, int B, int T, i
 // and the mask is resolved at compile time for every other tile.
 template <int DT, int NT, bool EXACT, int OCC>
 __global__ void __launch_bounds__(256, OCC)
-    attention_kernel(const uint16_t *__restrict__ qkv, uint16_t *__restrict__ ctx_out, int T, int heads) {
+    attention_kernel(const uint16_t *__restrict__ qkv, uint16_t *__restrict__ ctx_out, int T, int heads, int qt_lim) {
     using E = vm_elem<DT>;
     using vec8 = typename E::vec8;
     constexpr int KROWS = NT * 16;
@@ -387,11 +389,11 @@ __global__ void __launch_bounds__(256, OCC)
     }
     __syncthreads();
 
-    for (int qt = wave; qt < NT; qt += 4) {
+    for (int qt = wave; qt < qt_lim; qt += 4) {
         const int qtok = qt * 16 + r16;
         const bool qvalid = qtok < T;
         const vec8 qa = q0, qb = q1;
-        if (qt + 4 < NT) load_q(qt + 4, q0, q1);  // next tile's queries: their latency hides behind this tile
+        if (qt + 4 < qt_lim) load_q(qt + 4, q0, q1);  // next tile's queries: their latency hides behind this tile
 
         attend_tile<DT, NT, EXACT>(kl, vl, qa, qb, T, lane, qvalid,
                                    ctx_out + ((size_t)b * T + (qvalid ? qtok : 0)) * H + head * 64);
@@ -409,7 +411,7 @@ __global__ void __launch_bounds__(256, OCC)
 template <int DT, int NT, bool EXACT>
 __global__ void __launch_bounds__(576, 1)
     attention_stream_kernel(const uint16_t *__restrict__ qkv, uint16_t *__restrict__ ctx_out, int T, int heads,
-                            int items) {
+                            int items, int qt_lim) {  // qt_lim: query tiles (of 16 rows) to compute per item, <= NT
     using E = vm_elem<DT>;
     using vec8 = typename E::vec8;
     constexpr int ROWS = NT * 16;
@@ -437,6 +439,7 @@ __global__ void __launch_bounds__(576, 1)
                     qkv + ((size_t)((part == 2 ? 0 : part + 1) * heads + head) * M + (size_t)b * T) * 64);  // uniform
 #pragma unroll
                 for (int g = 0; g < ROWS / 8; ++g) {
+                    if (part == 2 && g >= 2 * qt_lim) break;  // query rows nobody asked for are not fetched
                     int key = g * 8 + srow;
                     if (!EXACT || g * 8 + 7 >= 16 * (NT - 1)) key = key > tmax ? tmax : key;  // groups that can pass T
                     const unsigned off = (unsigned)key * 128 + lane_off;  // 8 rows = one contiguous KiB
@@ -465,7 +468,7 @@ __global__ void __launch_bounds__(576, 1)
 #pragma unroll
         for (int u = 0; u < QT; ++u) {
             const int qt = wave + 8 * u;
-            if (qt < NT) {
+            if (qt < qt_lim) {
                 const int qtok = qt * 16 + r16;
                 const bool qvalid = qtok < T;
                 const vec8 qa = *reinterpret_cast<const vec8 *>(ql + qtok * 128 + ((h ^ (qtok & 7)) << 4));
@@ -478,7 +481,7 @@ __global__ void __launch_bounds__(576, 1)
 }
 
 template <int DT, int NT, bool EXACT>
-int launch_stream(vm_ctx *ctx, const uint16_t *qkv, uint16_t *out, int B, int T, int heads, hipStream_t st) {
+int launch_stream(vm_ctx *ctx, const uint16_t *qkv, uint16_t *out, int B, int T, int heads, hipStream_t st, int qt_lim) {
     const size_t lds = (size_t)NT * 16 * 128 * 6;
     auto kern = attention_stream_kernel<DT, NT, EXACT>;
     static bool attr_set = false;
@@ -489,13 +492,13 @@ int launch_stream(vm_ctx *ctx, const uint16_t *qkv, uint16_t *out, int B, int T,
     const int items = B * heads;
     const int grid = items < ctx->num_cus ? items : ctx->num_cus;
     vm_prof_scope prof(ctx, VM_PROF_ATTENTION, st);
-    kern<<<grid, 576, lds, st>>>(qkv, out, T, heads, items);
+    kern<<<grid, 576, lds, st>>>(qkv, out, T, heads, items, qt_lim < NT ? qt_lim : NT);
     VM_LAUNCH_CHECK(ctx);
     return VM_OK;
 }
 
 template <int DT, int NT, bool EXACT, int OCC = (NT <= 13 ? 2 : 1)>
-int launch(vm_ctx *ctx, const uint16_t *qkv, uint16_t *out, int B, int T, int heads, hipStream_t st) {
+int launch(vm_ctx *ctx, const uint16_t *qkv, uint16_t *out, int B, int T, int heads, hipStream_t st, int qt_lim) {
     const size_t lds = (size_t)NT * 16 * 128 * 2;
     auto kern = attention_kernel<DT, NT, EXACT, OCC>;
     static bool attr_set = false;
@@ -504,29 +507,30 @@ int launch(vm_ctx *ctx, const uint16_t *qkv, uint16_t *out, int B, int T, int he
         attr_set = true;
     }
     vm_prof_scope prof(ctx, VM_PROF_ATTENTION, st);
-    kern<<<B * heads, 256, lds, st>>>(qkv, out, T, heads);
+    kern<<<B * heads, 256, lds, st>>>(qkv, out, T, heads, qt_lim < NT ? qt_lim : NT);
     VM_LAUNCH_CHECK(ctx);
     return VM_OK;
 }
 
 template <int DT>
-int dispatch(vm_ctx *ctx, const uint16_t *qkv, uint16_t *out, int B, int T, int heads, hipStream_t st) {
+int dispatch(vm_ctx *ctx, const uint16_t *qkv, uint16_t *out, int B, int T, int heads, hipStream_t st, int q_rows) {
     const int nt = (T + 15) / 16;
+    const int ql = q_rows > 0 ? (q_rows + 15) / 16 : nt;  // query tiles wanted (clamped to the kernel's NT at launch)
     if (nt == 13) {  // ViT-B/16-224: 197 tokens
-        return launch_stream<DT, 13, true>(ctx, qkv, out, B, T, heads, st);
+        return launch_stream<DT, 13, true>(ctx, qkv, out, B, T, heads, st, ql);
     }
-    if (nt == 37) return launch_long<DT, 37, true>(ctx, qkv, out, B, T, heads, st);   // CLIP-L/14-336: 577 tokens
-    if (nt <= 2) return launch<DT, 2, false>(ctx, qkv, out, B, T, heads, st);
-    if (nt <= 5) return launch<DT, 5, false>(ctx, qkv, out, B, T, heads, st);
-    if (nt <= 13) return launch<DT, 13, false>(ctx, qkv, out, B, T, heads, st);
-    if (nt <= 37) return launch_long<DT, 37, false>(ctx, qkv, out, B, T, heads, st);
+    if (nt == 37) return launch_long<DT, 37, true>(ctx, qkv, out, B, T, heads, st, ql);   // CLIP-L/14-336: 577 tokens
+    if (nt <= 2) return launch<DT, 2, false>(ctx, qkv, out, B, T, heads, st, ql);
+    if (nt <= 5) return launch<DT, 5, false>(ctx, qkv, out, B, T, heads, st, ql);
+    if (nt <= 13) return launch<DT, 13, false>(ctx, qkv, out, B, T, heads, st, ql);
+    if (nt <= 37) return launch_long<DT, 37, false>(ctx, qkv, out, B, T, heads, st, ql);
     return vm_fail(ctx, VM_ERR_UNSUPPORTED, "attention: %d tokens > 592", T);
 }
 
 }  // namespace
 
 int vm_attention(vm_ctx *ctx, int dtype, const uint16_t *qkv, uint16_t *ctx_out, int B, int T, int heads,
-                 hipStream_t st) {
-    return dtype == VM_F16 ? dispatch<VM_F16>(ctx, qkv, ctx_out, B, T, heads, st)
-                           : dispatch<VM_BF16>(ctx, qkv, ctx_out, B, T, heads, st);
+                 hipStream_t st, int q_rows) {
+    return dtype == VM_F16 ? dispatch<VM_F16>(ctx, qkv, ctx_out, B, T, heads, st, q_rows)
+                           : dispatch<VM_BF16>(ctx, qkv, ctx_out, B, T, heads, st, q_rows);
 }

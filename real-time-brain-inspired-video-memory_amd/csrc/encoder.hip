@@ -568,18 +568,21 @@ extern "C" int vm_encode(vm_encoder *e, const void *patches, int B, void *out_em
         const int nb = B - b0 < mb ? B - b0 : mb;
         const int rows = nb * T;
         GemmArgs g;
-        int g_head_major = 0;
+        int g_head_major = 0, g_hm_rows = 0, g_hm_stride = 0;
         static int cls_env = -1;
         if (cls_env < 0) {
             const char *ev = getenv("VIDMEM_CLS_LAST");
-            cls_env = ev ? atoi(ev) : 1;
+            cls_env = ev ? atoi(ev) : 3;
         }
-        const bool cls_only = cls_env != 0;  // VIDMEM_CLS_LAST=0: the last layer's MLP on every row (developer A/B)
+        // VIDMEM_CLS_LAST (developer A/B): bit 0 = projection / LN2 / MLP of the last layer on the CLS rows only,
+        // bit 1 = also only the CLS rows' queries and query tile in its attention; 0 = everything on every row
+        const bool cls_only = (cls_env & 1) != 0;
         auto gemm16 = [&](const uint16_t *X, int ldx, const uint16_t *W, const float *bias, uint16_t *out, int M, int N,
                           int K, int epi, int cat, int ldo = 0) {
             memset(&g, 0, sizeof(g));
             g.X = X; g.W = W; g.bias = bias; g.out16 = out;
             g.M = M; g.N = N; g.K = K; g.ldx = ldx; g.ldo = ldo ? ldo : N; g.prof_cat = cat; g.head_major = g_head_major;
+            g.hm_rows = g_hm_rows; g.hm_stride = g_hm_stride;
             return vm_gemm(ctx, dt, g, epi, st);
         };
         // patch embedding: [nb*P, patch_k] x [H, patch_k]^T (+bias) -> 16-bit rows; then x32 = rows + pos (+cls) [+pre-LN]
@@ -594,23 +597,39 @@ extern "C" int vm_encode(vm_encoder *e, const void *patches, int B, void *out_em
             // x32 += proj(l-1) + fc2(l-1), written back once; a16 = LN1(x32)
             if ((rc = vm_resid_layernorm(ctx, dt, ws.x32, pend_proj, pend_fc2, pend_proj != nullptr, w.ln1_g, w.ln1_b,
                                          d.ln_eps, ws.a16, rows, H, st)) != VM_OK) return rc;
+            const bool last_cls = l == d.layers - 1 && cls_only;
             g_head_major = 1;  // q/k/v of one head as contiguous [rows, 64] blocks: attention streams whole KiB
-            rc = gemm16(ws.a16, H, w.qkv_w, w.qkv_b, ws.qkv16, rows, 3 * H, H, EPI_STORE16, VM_PROF_GEMM_QKV);
+            if (last_cls && (cls_env & 2)) {
+                // last layer: keys and values of every row, but only the CLS rows' queries (see below): the K / V
+                // weight rows [H, 3H) write the k and v blocks, then a GEMM over the nb CLS rows (row stride T) writes
+                // each head's query into row b*T of its q block
+                rc = gemm16(ws.a16, H, w.qkv_w + (size_t)H * H, w.qkv_b + H, ws.qkv16 + (size_t)d.heads * rows * 64, rows,
+                            2 * H, H, EPI_STORE16, VM_PROF_GEMM_QKV);
+                if (rc == VM_OK) {
+                    g_hm_rows = rows;
+                    g_hm_stride = T;
+                    rc = gemm16(ws.a16, T * H, w.qkv_w, w.qkv_b, ws.qkv16, nb, H, H, EPI_STORE16, VM_PROF_GEMM_CLS);
+                    g_hm_rows = g_hm_stride = 0;
+                }
+            } else {
+                rc = gemm16(ws.a16, H, w.qkv_w, w.qkv_b, ws.qkv16, rows, 3 * H, H, EPI_STORE16, VM_PROF_GEMM_QKV);
+            }
             g_head_major = 0;
             if (rc != VM_OK) return rc;
-            if ((rc = vm_attention(ctx, dt, ws.qkv16, ws.a16, nb, T, d.heads, st)) != VM_OK) return rc;
-            if (l == d.layers - 1 && cls_only) {
+            if ((rc = vm_attention(ctx, dt, ws.qkv16, ws.a16, nb, T, d.heads, st, last_cls && (cls_env & 2) ? 1 : 0)) != VM_OK)
+                return rc;
+            if (last_cls) {
                 // LAST layer: the embedding is pooled from the CLS row alone (vm_pool), and behind the attention every
                 // row depends only on itself - so projection, LN2, FC1 and FC2 run on the nb CLS rows, addressed in
                 // place with a row stride of T rows (GEMM ldx / ldo, LN rstride).  The other rows' branch outputs were
                 // never read by anything; the CLS rows get the same values bit for bit (every GEMM tiling accumulates
                 // an output in the same MFMA order).  6.2 % of ViT-B/16's FLOPs, 3.5 % of CLIP-L/14-336's.
                 const int TH = T * H;
-                if ((rc = gemm16(ws.a16, TH, w.proj_w, w.proj_b, ws.d16, nb, H, H, EPI_DELTA16, VM_PROF_GEMM_RESID, TH)) != VM_OK) return rc;
+                if ((rc = gemm16(ws.a16, TH, w.proj_w, w.proj_b, ws.d16, nb, H, H, EPI_DELTA16, VM_PROF_GEMM_CLS, TH)) != VM_OK) return rc;
                 if ((rc = vm_resid_layernorm(ctx, dt, ws.x32, ws.d16, nullptr, 0, w.ln2_g, w.ln2_b, d.ln_eps, ws.a16, nb,
                                              H, st, T)) != VM_OK) return rc;
-                if ((rc = gemm16(ws.a16, TH, w.fc1_w, w.fc1_b, ws.mlp16, nb, d.mlp, H, act_epi, VM_PROF_GEMM_ACT)) != VM_OK) return rc;
-                if ((rc = gemm16(ws.mlp16, d.mlp, w.fc2_w, w.fc2_b, ws.e16, nb, H, d.mlp, EPI_DELTA16, VM_PROF_GEMM_RESID, TH)) != VM_OK) return rc;
+                if ((rc = gemm16(ws.a16, TH, w.fc1_w, w.fc1_b, ws.mlp16, nb, d.mlp, H, act_epi, VM_PROF_GEMM_CLS)) != VM_OK) return rc;
+                if ((rc = gemm16(ws.mlp16, d.mlp, w.fc2_w, w.fc2_b, ws.e16, nb, H, d.mlp, EPI_DELTA16, VM_PROF_GEMM_CLS, TH)) != VM_OK) return rc;
             } else {
                 if ((rc = gemm16(ws.a16, H, w.proj_w, w.proj_b, ws.d16, rows, H, H, EPI_DELTA16, VM_PROF_GEMM_RESID)) != VM_OK) return rc;
                 // a16 = LN2(x32 + proj(l)); x32 itself is NOT rewritten here: the next LN1 (or the pool) folds both

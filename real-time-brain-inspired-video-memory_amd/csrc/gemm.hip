@@ -58,7 +58,8 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
 // Element index of out16[t, f]: row-major [M, ldo], or head-major [N/64][M][64] (each 64-feature head a contiguous
 // [M, 64] block: what the attention kernel streams; see vm_kernels.h).
 __device__ __forceinline__ size_t out16_index(const GemmArgs &g, int t, int f) {
-    return g.head_major ? ((((size_t)(f >> 6) * g.M + t) << 6) | (f & 63)) : (size_t)t * g.ldo + f;
+    return g.head_major ? ((((size_t)(f >> 6) * g.hm_rows + (size_t)t * g.hm_stride) << 6) | (f & 63))
+                        : (size_t)t * g.ldo + f;
 }
 
 // 16-bit outputs leave with the non-temporal (streaming) policy: a GEMM writes 130-530 MB that the next kernel reads
@@ -894,5 +895,7 @@ int vm_gemm(vm_ctx *ctx, int dtype, const GemmArgs &g, int epi, hipStream_t st) 
                        g.K);
     GemmArgs a = g;
     a.stream_out = (size_t)g.M * g.N * 2 > ((size_t)32 << 20);  // more than the 8 x 4 MiB of L2
+    if (a.hm_rows <= 0) a.hm_rows = g.M;
+    if (a.hm_stride <= 0) a.hm_stride = 1;
     return dtype == VM_F16 ? launch<VM_F16>(ctx, a, epi, st) : launch<VM_BF16>(ctx, a, epi, st);
 }

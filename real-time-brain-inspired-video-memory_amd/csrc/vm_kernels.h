@@ -26,6 +26,8 @@ struct GemmArgs {
     int P, T;           // EPI_PATCH only: patches per frame, tokens per frame
     int prof_cat;       // vm_prof_cat of this launch (bench.py's per-kernel breakdown)
     int head_major;     // 16-bit epilogues: out16 is [N/64][M][64] (per-head contiguous blocks) instead of [M, ldo]
+    int hm_rows, hm_stride;  // head-major only: rows per head block (0 = M) and the block row of GEMM row t = t * hm_stride
+                             // (0 = 1): lets a GEMM over the CLS rows alone write into the all-rows q blocks
     int stream_out;     // set by vm_gemm: the 16-bit output is larger than L2 and leaves with the non-temporal policy
 };
 
@@ -33,8 +35,10 @@ int vm_gemm(vm_ctx *ctx, int dtype, const GemmArgs &g, int epi, hipStream_t st);
 
 // qkv HEAD-MAJOR 16-bit [3*heads][B*T][64] (block index = {q,k,v} * heads + head; GemmArgs::head_major) ->
 // ctx [B*T, H] 16-bit row-major; head dim 64.
+// q_rows > 0: only the first q_rows query rows of every frame are needed (rounded up to 16-row tiles; the other rows
+// of ctx_out are left untouched)
 int vm_attention(vm_ctx *ctx, int dtype, const uint16_t *qkv, uint16_t *ctx_out, int B, int T, int heads,
-                 hipStream_t st);
+                 hipStream_t st, int q_rows = 0);
 
 // v = (x32[row] + delta16[row]) + deltaB16[row] (fp16 whatever `dtype`: EPI_DELTA16; either may be null);
 // x32[row] = v when write_x; out16[row] = LayerNorm(v) * gamma + beta

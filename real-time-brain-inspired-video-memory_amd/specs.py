@@ -18,7 +18,7 @@ SPECS = {"vit_b16_224": VIT_B16_224, "clip_l14_336": CLIP_L14_336}
 
 # algorithmic FLOPs per frame (2 * MACs of the GEMMs and of QK^T / PV).
 # executed=True: what vm_encode actually runs - the LAST layer's projection and MLP only on the CLS row, the one row the
-# pooled embedding is read from (csrc/encoder.hip): 33.05 instead of 35.13 GFLOP for ViT-B/16-224.
+# pooled embedding is read from (csrc/encoder.hip): 32.71 instead of 35.13 GFLOP for ViT-B/16-224.
 def flops_per_frame(spec, executed: bool = False) -> float:
     H, L, M, P = spec["hidden"], spec["layers"], spec["mlp"], spec["patch"]
     n = (spec["image"] // P) ** 2 + 1
@@ -27,5 +27,8 @@ def flops_per_frame(spec, executed: bool = False) -> float:
     patch = 2 * (n - 1) * (3 * P * P) * H
     total = L * (qkv_attn + branch) + patch
     if executed:
-        total -= branch - branch // n                    # last layer: one row instead of n
+        total -= branch - branch // n                    # last layer: one row instead of n ...
+        q = 2 * n * H * H                                # ... and only that row's query; QK^T / PV for one query TILE (16)
+        total -= q - q // n
+        total -= (2 * 2 * n * n * H) * (n - 16) // n
     return float(total)
