@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(256) resid_layernorm_kernel(float *__restrict_
                 v[r][i].w += e[r][i].w;
             }
         }
-        if (write_x) {
+        if (write_x > 1 ? row % write_x == 0 : write_x) {  // write_x = n > 1: only every n-th row's sum is read again
             float4 *xr = reinterpret_cast<float4 *>(x32 + (size_t)row * rstride * H);
 #pragma unroll
             for (int i = 0; i < VPL; ++i) st_f4<NT>(xr + lane + 64 * i, v[r][i]);
@@ -595,7 +595,9 @@ extern "C" int vm_encode(vm_encoder *e, const void *patches, int B, void *out_em
         for (int l = 0; l < d.layers; ++l) {
             const LayerW &w = e->layers[l];
             // x32 += proj(l-1) + fc2(l-1), written back once; a16 = LN1(x32)
-            if ((rc = vm_resid_layernorm(ctx, dt, ws.x32, pend_proj, pend_fc2, pend_proj != nullptr, w.ln1_g, w.ln1_b,
+            // (last layer: only the CLS rows' folded sums are read again - by LN2 and the pool - so only they are written)
+            const int fold = pend_proj == nullptr ? 0 : (l == d.layers - 1 && cls_only && T > 1 ? T : 1);
+            if ((rc = vm_resid_layernorm(ctx, dt, ws.x32, pend_proj, pend_fc2, fold, w.ln1_g, w.ln1_b,
                                          d.ln_eps, ws.a16, rows, H, st)) != VM_OK) return rc;
             const bool last_cls = l == d.layers - 1 && cls_only;
             g_head_major = 1;  // q/k/v of one head as contiguous [rows, 64] blocks: attention streams whole KiB

@@ -41,7 +41,7 @@ int vm_attention(vm_ctx *ctx, int dtype, const uint16_t *qkv, uint16_t *ctx_out,
                  hipStream_t st, int q_rows = 0);
 
 // v = (x32[row] + delta16[row]) + deltaB16[row] (fp16 whatever `dtype`: EPI_DELTA16; either may be null);
-// x32[row] = v when write_x; out16[row] = LayerNorm(v) * gamma + beta
+// x32[row] = v when write_x == 1, or when write_x = n > 1 and row % n == 0; out16[row] = LayerNorm(v) * gamma + beta
 // rstride: row r of the pass lives at row r * rstride of every array (1: dense; tokens per frame: the CLS rows only)
 int vm_resid_layernorm(vm_ctx *ctx, int dtype, float *x32, const uint16_t *delta16, const uint16_t *deltaB16,
                        int write_x, const float *gamma, const float *beta, float eps, uint16_t *out16, int rows, int H,
