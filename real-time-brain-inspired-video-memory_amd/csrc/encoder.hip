@@ -369,6 +369,7 @@ struct vm_encoder {
     float *patch_b, *cls, *pos, *pre_g, *pre_b, *ln_g, *ln_b;
     LayerW *layers;
     int micro_batch;
+    int cls_last;   // VIDMEM_CLS_LAST at creation (developer A/B; default 3): see vm_encode's last layer
 };
 
 static int round_up(int x, int a) { return (x + a - 1) / a * a; }
@@ -402,6 +403,8 @@ extern "C" int vm_encoder_create(vm_ctx *ctx, const vm_encoder_desc *desc, const
     }
     const char *mb = getenv("VIDMEM_MICROBATCH");
     e->micro_batch = mb ? atoi(mb) : 0;
+    const char *cl = getenv("VIDMEM_CLS_LAST");
+    e->cls_last = cl ? atoi(cl) : 3;
     const size_t H = d.hidden, M = d.mlp;
     // byte sizes in header order
     auto a256 = [](size_t b) { return vm_align_up(b, 256); };
@@ -569,13 +572,10 @@ extern "C" int vm_encode(vm_encoder *e, const void *patches, int B, void *out_em
         const int rows = nb * T;
         GemmArgs g;
         int g_head_major = 0, g_hm_rows = 0, g_hm_stride = 0;
-        static int cls_env = -1;
-        if (cls_env < 0) {
-            const char *ev = getenv("VIDMEM_CLS_LAST");
-            cls_env = ev ? atoi(ev) : 3;
-        }
-        // VIDMEM_CLS_LAST (developer A/B): bit 0 = projection / LN2 / MLP of the last layer on the CLS rows only,
-        // bit 1 = also only the CLS rows' queries and query tile in its attention; 0 = everything on every row
+        // VIDMEM_CLS_LAST, read when the encoder is created (developer A/B): bit 0 = projection / LN2 / MLP of the last
+        // layer on the CLS rows only, bit 1 = also only the CLS rows' queries and query tile in its attention; 0 =
+        // everything on every row
+        const int cls_env = e->cls_last;
         const bool cls_only = (cls_env & 1) != 0;
         auto gemm16 = [&](const uint16_t *X, int ldx, const uint16_t *W, const float *bias, uint16_t *out, int M, int N,
                           int K, int epi, int cat, int ldo = 0) {

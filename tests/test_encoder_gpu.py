@@ -185,6 +185,37 @@ def test_batching_is_invisible(monkeypatch):
     assert torch.isfinite(all_emb.float()).all()
 
 
+@pytest.mark.parametrize("dtype,image,patch,hidden,heads,n", [("f16", 224, 16, 768, 12, 130), ("bf16", 336, 14, 1024, 16, 40)])
+def test_last_layer_on_cls_rows_is_invisible(monkeypatch, dtype, image, patch, hidden, heads, n):
+    """vm_encode runs the LAST layer's query projection, attention query tile, attention projection, LN2 and MLP on the
+    CLS rows only (the one row the embedding is pooled from).  Against an encoder created with VIDMEM_CLS_LAST=0
+    (everything on every row) the embeddings must be identical BIT FOR BIT, for both attention kernels (197 / 577
+    tokens) and for batches that take the persistent 256 x 256 GEMM (n x tokens rows) as well as 3-frame ones."""
+    from vidmem import synthetic as syn, specs
+    base = specs.VIT_B16_224 if image == 224 else specs.CLIP_L14_336
+    spec = dict(base, layers=3)
+    assert (spec["image"], spec["patch"], spec["hidden"], spec["heads"]) == (image, patch, hidden, heads)
+    w = syn.encoder_weights(spec, seed=31)
+    frames = torch.from_numpy(syn.frames_u8(77, n, image, image)).cuda()
+    monkeypatch.setenv("VIDMEM_CLS_LAST", "0")           # read when the encoder is created
+    full = _encoder(spec, w, dtype)
+    monkeypatch.setenv("VIDMEM_CLS_LAST", "1")           # projection + MLP pruned, attention on every row
+    half = _encoder(spec, w, dtype)
+    monkeypatch.delenv("VIDMEM_CLS_LAST")
+    pruned = _encoder(spec, w, dtype)
+    want = full.embed_frames(frames)
+    assert torch.isfinite(want.float()).all()
+    assert torch.equal(half.embed_frames(frames), want)
+    assert torch.equal(pruned.embed_frames(frames), want)
+    assert torch.equal(pruned.embed_frames(frames[:3]), want[:3])
+    one = dict(spec, layers=1)                           # the last layer is also the first: no pending branch outputs
+    w1 = syn.encoder_weights(one, seed=32)
+    monkeypatch.setenv("VIDMEM_CLS_LAST", "0")
+    full1 = _encoder(one, w1, dtype)
+    monkeypatch.delenv("VIDMEM_CLS_LAST")
+    assert torch.equal(_encoder(one, w1, dtype).embed_frames(frames[:5]), full1.embed_frames(frames[:5]))
+
+
 @pytest.mark.parametrize("name,dtype,n", [("vit_b16_224", "f16", 500), ("clip_l14_336", "bf16", 120)])
 def test_bench_size_batches_take_the_big_kernels_and_agree(name, dtype, n):
     """BASELINE-size micro-batches (441 ViT-B frames / 112 CLIP-L frames per pass) run the persistent 256x256 GEMM
