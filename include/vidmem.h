@@ -47,7 +47,8 @@ enum vm_score_mode { VM_SCORE_RAW = 0, VM_SCORE_UNIT_INTERVAL = 1 };
 int vm_init(int device, vm_ctx **out);
 void vm_destroy(vm_ctx *ctx);
 const char *vm_last_error(vm_ctx *ctx);
-/* ABI version of this header (bumped on any signature change). */
+/* ABI version of this header (bumped on any signature change; 3: vm_encode_micro_batch, VM_PROF_GEMM_CLS - the arrays
+ * vm_profile_read fills grew to 14 entries). */
 int vm_abi_version(void);
 
 /* ---- frame preprocessing ------------------------------------------------------------------------------

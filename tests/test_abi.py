@@ -55,7 +55,7 @@ def test_no_gpu_means_loud_failure(built):
     assert e.value.code == built.VM_ERR_NO_DEVICE
     h = ctypes.c_void_p()
     assert built.lib().vm_init(0, ctypes.byref(h)) == built.VM_ERR_NO_DEVICE
-    assert built.lib().vm_abi_version() == 2
+    assert built.lib().vm_abi_version() == 3
 
 
 def test_product_package_never_imports_the_oracle():
