@@ -408,22 +408,22 @@ __global__ void __launch_bounds__(256, OCC)
 // through LDS too), so they never wait on the vector-memory counter and their context stores drain in the background.
 // (The loader is a wave of its own because vmcnt is per wave: the compiler guards every transposing LDS read with
 // vmcnt(0) while an LDS-DMA of the same wave is in flight, which would serialise the two.)
-template <int DT, int NT, bool EXACT>
-__global__ void __launch_bounds__(576, 1)
+template <int DT, int NT, bool EXACT, int CW>  // CW compute waves + 1 loader wave
+__global__ void __launch_bounds__((CW + 1) * 64, 1)
     attention_stream_kernel(const uint16_t *__restrict__ qkv, uint16_t *__restrict__ ctx_out, int T, int heads,
                             int items, int qt_lim) {  // qt_lim: query tiles (of 16 rows) to compute per item, <= NT
     using E = vm_elem<DT>;
     using vec8 = typename E::vec8;
     constexpr int ROWS = NT * 16;
     constexpr int IMG = 3 * ROWS * 128;   // K rows, V rows, Q rows
-    constexpr int QT = (NT + 7) / 8;      // query tiles per compute wave
+    constexpr int QT = (NT + CW - 1) / CW;  // query tiles per compute wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = heads * 64;
     if (blockIdx.x >= items) return;
 
-    if (wave == 8) {  // ---- loader ---------------------------------------------------------------------------
+    if (wave == CW) {  // ---- loader ---------------------------------------------------------------------------
         // per-lane constants: a wave instruction covers 8 rows x 128 B; lane -> (row srow, stored chunk scp), and
         // since every group starts at a multiple of 8 rows the source chunk (scp ^ row & 7) is fixed per lane
         const int srow = lane >> 3, scp = lane & 7;
@@ -467,7 +467,7 @@ __global__ void __launch_bounds__(576, 1)
         const int b = item / heads, head = item - b * heads;
 #pragma unroll
         for (int u = 0; u < QT; ++u) {
-            const int qt = wave + 8 * u;
+            const int qt = wave + CW * u;
             if (qt < qt_lim) {
                 const int qtok = qt * 16 + r16;
                 const bool qvalid = qtok < T;
@@ -480,10 +480,10 @@ __global__ void __launch_bounds__(576, 1)
     }
 }
 
-template <int DT, int NT, bool EXACT>
-int launch_stream(vm_ctx *ctx, const uint16_t *qkv, uint16_t *out, int B, int T, int heads, hipStream_t st, int qt_lim) {
+template <int DT, int NT, bool EXACT, int CW>
+int launch_stream_cw(vm_ctx *ctx, const uint16_t *qkv, uint16_t *out, int B, int T, int heads, hipStream_t st, int qt_lim) {
     const size_t lds = (size_t)NT * 16 * 128 * 6;
-    auto kern = attention_stream_kernel<DT, NT, EXACT>;
+    auto kern = attention_stream_kernel<DT, NT, EXACT, CW>;
     static bool attr_set = false;
     if (!attr_set) {
         VM_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -492,10 +492,24 @@ int launch_stream(vm_ctx *ctx, const uint16_t *qkv, uint16_t *out, int B, int T,
     const int items = B * heads;
     const int grid = items < ctx->num_cus ? items : ctx->num_cus;
     vm_prof_scope prof(ctx, VM_PROF_ATTENTION, st);
-    kern<<<grid, 576, lds, st>>>(qkv, out, T, heads, items, qt_lim < NT ? qt_lim : NT);
+    kern<<<grid, (CW + 1) * 64, lds, st>>>(qkv, out, T, heads, items, qt_lim < NT ? qt_lim : NT);
     VM_LAUNCH_CHECK(ctx);
     return VM_OK;
 }
+
+template <int DT, int NT, bool EXACT>
+int launch_stream(vm_ctx *ctx, const uint16_t *qkv, uint16_t *out, int B, int T, int heads, hipStream_t st, int qt_lim) {
+    // 13 compute waves (one query tile each, four waves per SIMD at <= 128 registers) + the loader; VIDMEM_ATTN_CW=8:
+    // eight compute waves with up to two tiles each (168 registers)
+    static int cw_env = -1;
+    if (cw_env < 0) {
+        const char *e = getenv("VIDMEM_ATTN_CW");
+        cw_env = e ? atoi(e) : 13;
+    }
+    if (cw_env == 8) return launch_stream_cw<DT, NT, EXACT, 8>(ctx, qkv, out, B, T, heads, st, qt_lim);
+    return launch_stream_cw<DT, NT, EXACT, 13>(ctx, qkv, out, B, T, heads, st, qt_lim);
+}
+
 
 template <int DT, int NT, bool EXACT, int OCC = (NT <= 13 ? 2 : 1)>
 int launch(vm_ctx *ctx, const uint16_t *qkv, uint16_t *out, int B, int T, int heads, hipStream_t st, int qt_lim) {
