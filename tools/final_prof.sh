@@ -1,5 +1,5 @@
 set -o pipefail
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r2u; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r2v; mkdir -p $O
 python $R/bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --no-cpu-baseline > $O/stats.log 2>&1; echo "stats rc=$?"
