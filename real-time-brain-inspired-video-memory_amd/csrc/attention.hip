@@ -160,7 +160,10 @@ __device__ __forceinline__ float attend_rowmax(const char *kl, typename vm_elem<
     return mx;
 }
 
-template <int DT, int NT, bool EXACT>
+// ONLINE: no first pass - the row maximum is tracked step by step and the running sums are rescaled (a wave-uniform
+// branch, taken only in the steps where some row's maximum grows).  Same softmax; the products exp2((s - m_t) c) *
+// exp2((m_t - m_final) c) differ from exp2((s - m_final) c) by fp32 roundings only.
+template <int DT, int NT, bool EXACT, bool ONLINE = false>
 __device__ __forceinline__ void attend_tile_pass2(const char *kl, const char *vl, typename vm_elem<DT>::vec8 qa,
                                                   typename vm_elem<DT>::vec8 qb, float mx, int T, int lane,
                                                   bool qvalid, uint16_t *dst_row) {
@@ -172,8 +175,10 @@ __device__ __forceinline__ void attend_tile_pass2(const char *kl, const char *vl
     const int r16 = lane & 15, h = lane >> 4;
     const int tq = r16 >> 2, tp = r16 & 3;
     const float scale_log2e = 0.125f * 1.44269504088896340736f;
-    const float neg_mxc = -mx * scale_log2e;
-    const f32x2 c2 = {scale_log2e, scale_log2e}, n2 = {neg_mxc, neg_mxc};
+    float run_m = ONLINE ? -1e30f : mx;  // running (ONLINE) or known row maximum
+    float neg_mxc = -run_m * scale_log2e;
+    const f32x2 c2 = {scale_log2e, scale_log2e};
+    f32x2 n2 = {neg_mxc, neg_mxc};
     const char *p0 = kl + r16 * 128 + ((h ^ (r16 & 7)) << 4);
     const char *p1 = kl + r16 * 128 + (((h + 4) ^ (r16 & 7)) << 4);
     // V fragments: rows 32*ks + 4h + tq (+16); (row & 7) == ((4h + tq) & 7) for every step -> per-lane constants
@@ -216,6 +221,22 @@ __device__ __forceinline__ void attend_tile_pass2(const char *kl, const char *vl
         } else if (masked1) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) a[1][j] = ((2 * ks + 1) * 16 + 4 * h + j < T) ? a[1][j] : -INFINITY;
+        }
+        if (ONLINE) {
+            float lm = fmaxf(fmaxf(fmaxf(a[0][0], a[0][1]), fmaxf(a[0][2], a[0][3])),
+                             fmaxf(fmaxf(a[1][0], a[1][1]), fmaxf(a[1][2], a[1][3])));
+            lm = fmaxf(lm, __shfl_xor(lm, 16, 64));
+            lm = fmaxf(lm, __shfl_xor(lm, 32, 64));
+            if (__ballot(lm > run_m) != 0ull) {  // wave-uniform: some query row of this tile has a new maximum
+                const float m_new = fmaxf(run_m, lm);
+                const float f = __builtin_amdgcn_exp2f((run_m - m_new) * scale_log2e);  // 1 where nothing changed
+                sum2 *= f32x2{f, f};
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) o[dt] *= f32x4{f, f, f, f};
+                run_m = m_new;
+                neg_mxc = -run_m * scale_log2e;
+                n2 = f32x2{neg_mxc, neg_mxc};
+            }
         }
         uint16_t pe[8];
 #pragma unroll
@@ -266,7 +287,7 @@ __device__ __forceinline__ void attend_tile_pass2(const char *kl, const char *vl
 
 // One workgroup of NW waves per (frame, head): K rows by LDS-DMA, barrier; the V rows' LDS-DMA is issued next and
 // lands while every wave runs pass 1 of its first query tile; then tiles wave, wave + NW, ...
-template <int DT, int NT, bool EXACT, int NW>
+template <int DT, int NT, bool EXACT, int NW, bool ONLINE>
 __global__ void __launch_bounds__(NW * 64, 1)
     attention_long_kernel(const uint16_t *__restrict__ qkv, uint16_t *__restrict__ ctx_out, int T, int heads,
                           int qt_lim) {
@@ -307,7 +328,7 @@ __global__ void __launch_bounds__(NW * 64, 1)
     __syncthreads();
     stage(2, vl);
     float mx = 0.f;
-    if (wave < qt_lim) mx = attend_rowmax<DT, NT, EXACT>(kl, q0, q1, T, lane);  // needs K only: overlaps the V fill
+    if (!ONLINE && wave < qt_lim) mx = attend_rowmax<DT, NT, EXACT>(kl, q0, q1, T, lane);  // needs K only: overlaps the V fill
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int qt = wave; qt < qt_lim; qt += NW) {
@@ -315,8 +336,8 @@ __global__ void __launch_bounds__(NW * 64, 1)
         const bool qvalid = qtok < T;
         const vec8 qa = q0, qb = q1;
         if (qt + NW < qt_lim) load_q(qt + NW, q0, q1);
-        if (qt != wave) mx = attend_rowmax<DT, NT, EXACT>(kl, qa, qb, T, lane);
-        attend_tile_pass2<DT, NT, EXACT>(kl, vl, qa, qb, mx, T, lane, qvalid,
+        if (!ONLINE && qt != wave) mx = attend_rowmax<DT, NT, EXACT>(kl, qa, qb, T, lane);
+        attend_tile_pass2<DT, NT, EXACT, ONLINE>(kl, vl, qa, qb, mx, T, lane, qvalid,
                                          ctx_out + ((size_t)b * T + (qvalid ? qtok : 0)) * H + head * 64);
     }
 }
@@ -325,14 +346,29 @@ template <int DT, int NT, bool EXACT>
 int launch_long(vm_ctx *ctx, const uint16_t *qkv, uint16_t *out, int B, int T, int heads, hipStream_t st, int qt_lim) {
     const size_t lds = (size_t)NT * 16 * 128 * 2;
     // 16 waves (4 per SIMD; the kernel needs ~80 VGPRs): 21.1 ms vs 27.0 ms with 8 waves per 256-frame CLIP-L pass
-    auto kern = attention_long_kernel<DT, NT, EXACT, 16>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        VM_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+    static int online_env = -1;
+    if (online_env < 0) {
+        const char *e = getenv("VIDMEM_ATTN_ONLINE");
+        online_env = e ? atoi(e) : 1;
     }
     vm_prof_scope prof(ctx, VM_PROF_ATTENTION, st);
-    kern<<<B * heads, 1024, lds, st>>>(qkv, out, T, heads, qt_lim < NT ? qt_lim : NT);
+    if (online_env) {
+        auto kern = attention_long_kernel<DT, NT, EXACT, 16, true>;
+        static bool attr_set = false;
+        if (!attr_set) {
+            VM_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        kern<<<B * heads, 1024, lds, st>>>(qkv, out, T, heads, qt_lim < NT ? qt_lim : NT);
+    } else {
+        auto kern = attention_long_kernel<DT, NT, EXACT, 16, false>;
+        static bool attr_set = false;
+        if (!attr_set) {
+            VM_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        kern<<<B * heads, 1024, lds, st>>>(qkv, out, T, heads, qt_lim < NT ? qt_lim : NT);
+    }
     VM_LAUNCH_CHECK(ctx);
     return VM_OK;
 }
