@@ -70,8 +70,9 @@ def test_preprocess_ref_patch_layout_is_a_permutation():
     assert pat[0, 5, 2 * 196 + 3 * 14 + 7] == chw[0, 2, 1 * 14 + 3, 1 * 14 + 7]
 
 
-def test_extractor_sources_and_json_shape(tmp_path):
+def test_extractor_sources_and_json_shape(tmp_path, monkeypatch):
     """Array source + JSON layout of FrameEmbeddingExtractor without touching the GPU (encoder/memory stubbed)."""
+    monkeypatch.chdir(tmp_path)  # metrics/vlm_<run>.json and logs/ land where the caller runs, not in the repo
     import asyncio
     from types import SimpleNamespace
     from vidmem import extractor as X

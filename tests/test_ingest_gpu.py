@@ -53,13 +53,14 @@ def test_next_slot_commit_in_place():
         assert np.array_equal(got.cpu().numpy(), want[-1])
 
 
-def test_extractor_pipeline_matches_direct_path(tmp_path):
+def test_extractor_pipeline_matches_direct_path(tmp_path, monkeypatch):
     """process_video on an .npz clip: embeddings appended to the memory and the neighbours written to the JSON equal
     what the plain calls (device tensor in, no staging) give chunk by chunk."""
     from vidmem import specs, synthetic as syn
     from vidmem.encoder import FrameEncoder
     from vidmem.memory import EmbeddingMemory
     from vidmem.extractor import FrameEmbeddingExtractor, chunk_plan
+    monkeypatch.chdir(tmp_path)  # metrics/ and logs/ land where the caller runs
     spec = dict(specs.VIT_B16_224, layers=2)
     enc = FrameEncoder(spec, syn.encoder_weights(spec, seed=8), "f16")
     frames = syn.frames_u8(77, 50, 120, 200)
