@@ -772,28 +772,39 @@ int run_topk_kl(vm_memory *m, const ScanPlan &p, const void *queries, int Q, int
     // everything below it (list scan) or emits only what is at or above it (emit scan, topk_emit.hip).
     const bool emit = p.emit;
     if (emit) {
-        // Cut cascade, all on the emit kernel (topk_emit.hip): (A) the first s0 rows with no cut -> their KL-th best;
-        // (B) the sample rows against that cut -> the KL-th best of the sample (~16 KL candidates per query);
-        // (C) every row against the sample's cut (~rows * KL / sample candidates, kept near 1 k for any memory size).
-        // Each cut is the KL-th best of a SUBSET of the rows, so at least KL rows are at or above it.
+        // Cut cascade (topk_emit.hip / topk_gscan.hip), INCREMENTAL: pass 0 keeps every score of the physically first
+        // s0 rows; pass p scans only the slots [limit[p-1], limit[p]) against the KL-th best of the rows before them
+        // and appends to the KL survivors the compact kernel seeded the buffer with.  Each cut is the KL-th best of a
+        // SUBSET of the rows, so the KL best of that subset plus everything at or above the cut among the other rows
+        // contain the KL best overall; no row is scanned twice.  With the limits growing 8-fold a pass emits about
+        // 7 KL candidates per query whatever the memory size (the previous three-pass cascade re-scanned the sample
+        // and emitted rows * KL / sample ~ 1 k per query in its last pass: at 7,040 queries a quarter of all 16 x 16
+        // score blocks then took the emission path).
         int *cand_cnt = (int *)((char *)thr_s + vm_align_up((size_t)p.q_pad * 8, 256));
         int *mk = (int *)((char *)cand_cnt + vm_align_up((size_t)p.q_pad * 4, 256));
         float *cand_s = (float *)((char *)mk + vm_align_up((size_t)p.q_pad * 4, 256));
         int *cand_o = (int *)((char *)cand_s + vm_align_up((size_t)p.q_pad * VM_EMIT_CAP * 4, 256));
-        const int64_t sample = m->cap / 64 > SAMPLE_ROWS ? (m->cap / 64 + 31) / 32 * 32 : SAMPLE_ROWS;
-        // pass A keeps EVERY score of the physically first s0 rows (slot = physical row index, dense)
-        const int64_t s0 = VM_EMIT_CAP;
-        const int64_t limits[3] = {s0, sample, INT64_MAX};
-        for (int pass = 0; pass < 3; ++pass) {
-            hipError_t e = hipMemsetAsync(cand_cnt, 0, vm_align_up((size_t)p.q_pad * 4, 256), st);
-            if (e != hipSuccess) return vm_fail(m->ctx, VM_ERR_HIP, "memset: %s", hipGetErrorString(e));
-            if ((rc = vm_topk_emit_scan(m, queries, Q, pass ? thr_s : nullptr, pass ? thr_o : nullptr, cand_cnt, cand_s,
-                                        cand_o, limits[pass], st)) != VM_OK)
+        static int growth = -1;
+        if (growth < 0) {
+            const char *e = getenv("VIDMEM_CUT_GROWTH");
+            growth = e ? atoi(e) : 8;
+            if (growth < 2) growth = 2;
+        }
+        // cand_cnt and mk are neighbours: one memset clears both
+        hipError_t e = hipMemsetAsync(cand_cnt, 0, 2 * vm_align_up((size_t)p.q_pad * 4, 256), st);
+        if (e != hipSuccess) return vm_fail(m->ctx, VM_ERR_HIP, "memset: %s", hipGetErrorString(e));
+        int64_t begin = 0, limit = VM_EMIT_CAP;  // pass 0: slot = physical row index, dense
+        for (int pass = 0;; ++pass) {
+            const bool last = limit >= m->cap;
+            if ((rc = vm_topk_emit_scan(m, queries, Q, p.q_pad, pass ? thr_s : nullptr, pass ? thr_o : nullptr, cand_cnt,
+                                        cand_s, cand_o, begin, last ? INT64_MAX : limit, st)) != VM_OK)
                 return rc;
-            const bool last = pass == 2;
-            if ((rc = vm_topk_emit_compact(m, Q, KL, cand_cnt, cand_s, cand_o, part_s, part_o, last ? mk : nullptr,
-                                           last ? nullptr : thr_s, last ? nullptr : thr_o, st)) != VM_OK)
+            if ((rc = vm_topk_emit_compact(m, Q, KL, cand_cnt, cand_s, cand_o, part_s, part_o, mk, last ? nullptr : thr_s,
+                                           last ? nullptr : thr_o, last ? 0 : 1, st)) != VM_OK)
                 return rc;
+            if (last) break;
+            begin = limit;
+            limit *= growth;
         }
         mark = mk;
         fin_nblk = 1;

@@ -70,8 +70,8 @@ __global__ void __launch_bounds__(EM_THREADS, 1)
     topk_emit_kernel(const uint16_t *__restrict__ mem, const float *__restrict__ rnorm,
                      const uint16_t *__restrict__ queries, const int64_t *__restrict__ d_total, int64_t cap, int ring,
                      int Q, const float *__restrict__ thr_s, const int *__restrict__ thr_o, int *__restrict__ cand_cnt,
-                     float *__restrict__ cand_s, int *__restrict__ cand_o, int nsuper, int64_t row_limit,
-                     int nt_rows) {
+                     float *__restrict__ cand_s, int *__restrict__ cand_o, int nsuper, int64_t row_begin,
+                     int64_t row_limit, int nt_rows) {
     using E = vm_elem<DT>;
     using vec8 = typename E::vec8;
     constexpr int D = 128 * KS;
@@ -139,9 +139,10 @@ __global__ void __launch_bounds__(EM_THREADS, 1)
     }
 
     RingView rv = ring_view(*d_total, cap, ring);
-    if (rv.n > row_limit) rv.n = row_limit;  // cut cascade: the sample passes scan only the first row_limit slots
-    const int64_t ntiles = (rv.n + EM_ROWS - 1) / EM_ROWS;
-    const int64_t my_tiles = bx < ntiles ? (ntiles - bx + nbx - 1) / nbx : 0;   // tiles bx, bx + nbx, ...
+    if (rv.n > row_limit) rv.n = row_limit;  // cut cascade: a pass scans the physical slots [row_begin, row_limit) only
+    const int64_t tile0 = row_begin / EM_ROWS;                                  // row_begin is a multiple of EM_ROWS
+    const int64_t ntiles = rv.n > row_begin ? (rv.n + EM_ROWS - 1) / EM_ROWS - tile0 : 0;
+    const int64_t my_tiles = bx < ntiles ? (ntiles - bx + nbx - 1) / nbx : 0;   // tiles tile0 + bx, + nbx, ...
 
     // LDS-DMA of one tile: piece p covers LDS bytes [1024 p, 1024 p + 1024) of the stage; lane -> (row, chunk') of the
     // linear image; the source chunk is chunk' ^ (row & 15) (swizzle on the source address, the reads apply it again)
@@ -199,10 +200,10 @@ __global__ void __launch_bounds__(EM_THREADS, 1)
     // prologue: DEEP fills every stage, the shallow schedule leaves one free for the tile staged during the first compute
 #pragma unroll
     for (int s = 0; s < (DEEP ? STAGES : STAGES - 1); ++s)
-        if (s < my_tiles) stage_tile(bx + (int64_t)s * nbx, s);
+        if (s < my_tiles) stage_tile(tile0 + bx + (int64_t)s * nbx, s);
 
     for (int64_t it = 0; it < my_tiles; ++it) {
-        const int64_t tile = bx + it * nbx;
+        const int64_t tile = tile0 + bx + it * nbx;
         const int buf = (int)(it % STAGES);
         bool do_stage, spread;
         int64_t ntile;
@@ -396,13 +397,17 @@ __global__ void __launch_bounds__(EM_THREADS, 1)
 // the prefix, Hillis-Steele suffix sums over the 256 bins), then everything at or above it - all ties included - is
 // ranked by (score desc, order asc).  (Two earlier versions - a bitwise search with a block reduction per bit, KL
 // rounds of block arg-best - spent 18-24 us per launch in chains of dependent cross-lane shuffles.)
-// mark[q] = 1 when the buffer overflowed or more ties sit at the KL-th place than are ranked here: finalize then
-// flags the query for the exhaustive redo.
+// mark[q] is SET (never cleared: the caller zeroes it once per search) when the buffer overflowed or more ties sit at
+// the KL-th place than are ranked here: finalize then flags the query for the exhaustive redo.
+// seed != 0 (every pass of the cut cascade but the last): the ranked list is also written back to the head of the
+// query's candidate buffer and cand_cnt[q] set to its length, so the next pass scans only the rows this one did not
+// see and APPENDS to it - the KL best of a subset plus everything at or above their KL-th in the rest contain the KL
+// best of the union.
 constexpr int CP_SURV = 512;
 __global__ void __launch_bounds__(CP_THREADS)
-    topk_compact_kernel(const int *__restrict__ cand_cnt, const float *__restrict__ cand_s,
-                        const int *__restrict__ cand_o, int KL, float *__restrict__ part_s, int *__restrict__ part_o,
-                        int *__restrict__ mark, float *__restrict__ cut_s, int *__restrict__ cut_o) {
+    topk_compact_kernel(int *__restrict__ cand_cnt, float *__restrict__ cand_s, int *__restrict__ cand_o, int KL,
+                        float *__restrict__ part_s, int *__restrict__ part_o, int *__restrict__ mark,
+                        float *__restrict__ cut_s, int *__restrict__ cut_o, int seed) {
     __shared__ int hist[2][CP_THREADS];
     __shared__ float sv_s[CP_SURV];
     __shared__ int sv_o[CP_SURV];
@@ -493,18 +498,25 @@ __global__ void __launch_bounds__(CP_THREADS)
         if (rank < KL) {
             ps[rank] = s;
             po[rank] = o;
+            if (seed) {  // every key of this block sits in registers and the survivors in LDS: the buffer is free
+                cand_s[(size_t)q * VM_EMIT_CAP + rank] = s;
+                cand_o[(size_t)q * VM_EMIT_CAP + rank] = o;
+            }
             if (cut_s && rank == KL - 1) {
                 cut_s[q] = s;
                 cut_o[q] = o;
             }
         }
     }
-    if (tid == 0 && mark) mark[q] = (cnt > VM_EMIT_CAP || too_many) ? 1 : 0;
+    if (tid == 0) {
+        if (mark && (cnt > VM_EMIT_CAP || too_many)) mark[q] = 1;
+        if (seed) cand_cnt[q] = S < KL ? S : KL;  // ranks 0 .. min(S, KL) - 1 are all taken (distinct orders)
+    }
 }
 
 template <int DT, int KS, int NG, bool DEEP>
 int launch_emit(vm_memory *m, const void *queries, int Q, const float *thr_s, const int *thr_o, int *cand_cnt,
-                float *cand_s, int *cand_o, int64_t row_limit, hipStream_t st) {
+                float *cand_s, int *cand_o, int64_t row_begin, int64_t row_limit, hipStream_t st) {
     constexpr int D = 128 * KS;
     constexpr int STAGES = KS <= 6 ? 3 : 2;
     const size_t lds = (size_t)STAGES * (EM_ROWS * 2 * D + 256) + (size_t)EM_WAVES * EM_WBUF * 12;
@@ -518,25 +530,27 @@ int launch_emit(vm_memory *m, const void *queries, int Q, const float *thr_s, co
     const int nsuper = (Q + EM_QPB * NG - 1) / (EM_QPB * NG);
     int nbx = m->ctx->num_cus / nsuper;
     if (nbx < 1) nbx = 1;
-    const int64_t rows = m->cap < row_limit ? m->cap : row_limit;
-    const int64_t ntiles = (rows + EM_ROWS - 1) / EM_ROWS;
+    const int64_t rows = (m->cap < row_limit ? m->cap : row_limit) - row_begin;
+    const int64_t ntiles = rows > 0 ? (rows + EM_ROWS - 1) / EM_ROWS : 1;
     if (nbx > ntiles) nbx = (int)ntiles;
     static int nt_env = -1;
     if (nt_env < 0) {
         const char *e = getenv("VIDMEM_TOPK_NT");
         nt_env = e ? atoi(e) : 1;
     }
-    const int nt_rows = nt_env && nsuper == 1 && row_limit >= m->cap;  // the full pass of a one-superblock search
+    // one superblock, and a pass that reads (nearly) the whole memory: every row byte is read once and never again
+    const int nt_rows = nt_env && nsuper == 1 && row_limit >= m->cap && row_begin * 2 <= m->cap;
     vm_prof_scope prof(m->ctx, VM_PROF_TOPK_SCAN, st);
     kern<<<nbx * nsuper, EM_THREADS, lds, st>>>(m->rows, m->rnorm32, (const uint16_t *)queries, m->d_total, m->cap,
-                                               m->ring, Q, thr_s, thr_o, cand_cnt, cand_s, cand_o, nsuper, row_limit, nt_rows);
+                                               m->ring, Q, thr_s, thr_o, cand_cnt, cand_s, cand_o, nsuper, row_begin,
+                                               row_limit, nt_rows);
     VM_LAUNCH_CHECK(m->ctx);
     return VM_OK;
 }
 
 template <int DT, int KS>
 int launch_emit_ng(vm_memory *m, const void *queries, int Q, const float *thr_s, const int *thr_o, int *cand_cnt,
-                   float *cand_s, int *cand_o, int64_t row_limit, hipStream_t st) {
+                   float *cand_s, int *cand_o, int64_t row_begin, int64_t row_limit, hipStream_t st) {
     static int deep_env = -1;
     if (deep_env < 0) {
         const char *e = getenv("VIDMEM_EMIT_DEEP");
@@ -548,13 +562,13 @@ int launch_emit_ng(vm_memory *m, const void *queries, int Q, const float *thr_s,
     if constexpr (KS <= 6) {  // two query groups per wave need 2 x 16 KS registers for the queries alone (192 of 256 at
         if (Q > EM_QPB) {     // D = 768: checked spill-free with -Rpass-analysis=kernel-resource-usage)
             if (deep_env & 2)
-                return launch_emit<DT, KS, 2, true>(m, queries, Q, thr_s, thr_o, cand_cnt, cand_s, cand_o, row_limit, st);
-            return launch_emit<DT, KS, 2, false>(m, queries, Q, thr_s, thr_o, cand_cnt, cand_s, cand_o, row_limit, st);
+                return launch_emit<DT, KS, 2, true>(m, queries, Q, thr_s, thr_o, cand_cnt, cand_s, cand_o, row_begin, row_limit, st);
+            return launch_emit<DT, KS, 2, false>(m, queries, Q, thr_s, thr_o, cand_cnt, cand_s, cand_o, row_begin, row_limit, st);
         }
     }
     if (deep_env & 1)
-        return launch_emit<DT, KS, 1, true>(m, queries, Q, thr_s, thr_o, cand_cnt, cand_s, cand_o, row_limit, st);
-    return launch_emit<DT, KS, 1, false>(m, queries, Q, thr_s, thr_o, cand_cnt, cand_s, cand_o, row_limit, st);
+        return launch_emit<DT, KS, 1, true>(m, queries, Q, thr_s, thr_o, cand_cnt, cand_s, cand_o, row_begin, row_limit, st);
+    return launch_emit<DT, KS, 1, false>(m, queries, Q, thr_s, thr_o, cand_cnt, cand_s, cand_o, row_begin, row_limit, st);
 }
 
 }  // namespace
@@ -575,14 +589,21 @@ size_t vm_topk_emit_workspace_bytes(int q_pad) {
     return vm_align_up((size_t)q_pad * 4, 256) * 2 + 2 * vm_align_up((size_t)q_pad * VM_EMIT_CAP * 4, 256);
 }
 
-// cand_cnt must be zero when the scan starts (the caller memsets it on the stream)
-int vm_topk_emit_scan(vm_memory *m, const void *queries, int Q, const float *thr_s, const int *thr_o, int *cand_cnt,
-                      float *cand_s, int *cand_o, int64_t row_limit, hipStream_t st) {
+// Scans the physical slots [row_begin, min(n, row_limit)) and APPENDS the candidates (cand_cnt: zero, or the seed
+// count the previous pass's compact left).  thr_s == null (dense pass): row_begin = 0 and cand_cnt zero.
+// Very many queries over many rows take the GEMM-class scan (topk_gscan.hip).
+int vm_topk_emit_scan(vm_memory *m, const void *queries, int Q, int q_thr, const float *thr_s, const int *thr_o,
+                      int *cand_cnt, float *cand_s, int *cand_o, int64_t row_begin, int64_t row_limit, hipStream_t st) {
+    if (row_begin % EM_ROWS != 0 || (!thr_s && row_begin != 0))
+        return vm_fail(m->ctx, VM_ERR_INVALID, "emit scan: row_begin %lld", (long long)row_begin);
+    if (thr_s && row_begin % 256 == 0 &&
+        vm_topk_gscan_supported(m, Q, (m->cap < row_limit ? m->cap : row_limit) - row_begin))
+        return vm_topk_gscan(m, queries, Q, q_thr, thr_s, thr_o, cand_cnt, cand_s, cand_o, row_begin, row_limit, st);
     const int ks = m->D / 128;
 #define GO(KSV)                                                                                                   \
     return m->dtype == VM_F16                                                                                     \
-               ? launch_emit_ng<VM_F16, KSV>(m, queries, Q, thr_s, thr_o, cand_cnt, cand_s, cand_o, row_limit, st) \
-               : launch_emit_ng<VM_BF16, KSV>(m, queries, Q, thr_s, thr_o, cand_cnt, cand_s, cand_o, row_limit, st)
+               ? launch_emit_ng<VM_F16, KSV>(m, queries, Q, thr_s, thr_o, cand_cnt, cand_s, cand_o, row_begin, row_limit, st) \
+               : launch_emit_ng<VM_BF16, KSV>(m, queries, Q, thr_s, thr_o, cand_cnt, cand_s, cand_o, row_begin, row_limit, st)
     switch (ks) {
         case 1: GO(1);
         case 2: GO(2);
@@ -594,10 +615,10 @@ int vm_topk_emit_scan(vm_memory *m, const void *queries, int Q, const float *thr
 #undef GO
 }
 
-int vm_topk_emit_compact(vm_memory *m, int Q, int KL, const int *cand_cnt, const float *cand_s, const int *cand_o,
-                         float *part_s, int *part_o, int *mark, float *cut_s, int *cut_o, hipStream_t st) {
+int vm_topk_emit_compact(vm_memory *m, int Q, int KL, int *cand_cnt, float *cand_s, int *cand_o, float *part_s,
+                         int *part_o, int *mark, float *cut_s, int *cut_o, int seed, hipStream_t st) {
     vm_prof_scope prof(m->ctx, VM_PROF_TOPK_FINALIZE, st);
-    topk_compact_kernel<<<Q, CP_THREADS, 0, st>>>(cand_cnt, cand_s, cand_o, KL, part_s, part_o, mark, cut_s, cut_o);
+    topk_compact_kernel<<<Q, CP_THREADS, 0, st>>>(cand_cnt, cand_s, cand_o, KL, part_s, part_o, mark, cut_s, cut_o, seed);
     VM_LAUNCH_CHECK(m->ctx);
     return VM_OK;
 }

@@ -39,7 +39,11 @@ __host__ __device__ inline RingView ring_view(int64_t total, int64_t cap, int ri
 constexpr int VM_EMIT_CAP = 4096;  // candidate slots per query; more -> the query is marked for the exhaustive redo
 bool vm_topk_emit_supported(const vm_memory *m, int Q, int KL);
 size_t vm_topk_emit_workspace_bytes(int q_pad);
-int vm_topk_emit_scan(vm_memory *m, const void *queries, int Q, const float *thr_s, const int *thr_o, int *cand_cnt,
-                      float *cand_s, int *cand_o, int64_t row_limit, hipStream_t st);
-int vm_topk_emit_compact(vm_memory *m, int Q, int KL, const int *cand_cnt, const float *cand_s, const int *cand_o,
-                         float *part_s, int *part_o, int *mark, float *cut_s, int *cut_o, hipStream_t st);
+int vm_topk_emit_scan(vm_memory *m, const void *queries, int Q, int q_thr, const float *thr_s, const int *thr_o,
+                      int *cand_cnt, float *cand_s, int *cand_o, int64_t row_begin, int64_t row_limit, hipStream_t st);
+int vm_topk_emit_compact(vm_memory *m, int Q, int KL, int *cand_cnt, float *cand_s, int *cand_o, float *part_s,
+                         int *part_o, int *mark, float *cut_s, int *cut_o, int seed, hipStream_t st);
+// ---- GEMM-class scan for very many queries (topk_gscan.hip), reached through vm_topk_emit_scan ---------------------
+bool vm_topk_gscan_supported(const vm_memory *m, int Q, int64_t rows);
+int vm_topk_gscan(vm_memory *m, const void *queries, int Q, int q_thr, const float *thr_s, const int *thr_o,
+                  int *cand_cnt, float *cand_s, int *cand_o, int64_t row_begin, int64_t row_limit, hipStream_t st);

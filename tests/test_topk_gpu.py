@@ -357,3 +357,107 @@ def test_full_size_properties_1m_rows_bf16_k20():
         s2, r2 = mem.topk(q[6:7], k, exact=True)
         assert np.array_equal(r2.cpu().numpy(), r_np[6:7]) and np.array_equal(s2.cpu().numpy(), s_np[6:7])
         assert mem.uncertified_count == 0
+
+
+def _oracle_rows_parallel(qbits, mbits, k, dtype, picks, threads=8):
+    """cref.cosine_topk for a subset of the queries, a few at a time on a thread pool (ctypes releases the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
+    groups = np.array_split(np.asarray(picks), threads)
+    with ThreadPoolExecutor(threads) as ex:
+        outs = list(ex.map(lambda g: cref.cosine_topk(qbits[g], mbits, k, dtype=dtype), groups))
+    return np.concatenate([o[0] for o in outs]), np.concatenate([o[1] for o in outs])
+
+
+def test_gemm_class_scan_7040_queries_bit_exact():
+    """The query count an 8-GPU step brings to every shard (BASELINE configs[3]: 8 x 880 = 7,040 queries per search)
+    takes the GEMM-class scan (csrc/topk_gscan.hip: 256-row x 256-query tiles, emit epilogue, incremental cut cascade)
+    on a 100k-row shard.  EVERY query against the exhaustive fp64 kernel bit for bit, and 160 of them - spread over
+    every query tile, wave column and lane position, the ragged last tile included - against the C oracle, with near
+    duplicates, exact duplicates on both sides of the cascade's pass boundaries, a zero query and a zero row."""
+    from vidmem import synthetic as syn
+    D, M, Q, k = 768, 100_000, 7040, 10
+    m = torch.from_numpy(syn.unit_rows(7, "memory100k", M, D)).to(torch.float16)
+    rng = np.random.default_rng(77)
+    q = torch.tensor(rng.standard_normal((Q, D)), dtype=torch.float32).to(torch.float16)
+    near = rng.integers(0, M, 400)
+    q[:400] = (0.6 * m[near].float() + 0.4 * q[:400].float()).to(torch.float16)
+    for a, b in ((12, 4095), (12, 4096), (30_000, 32_768), (40_000, 99_999), (5, 60_000)):
+        m[b] = m[a]                        # exact duplicates straddling the cascade's limits: lower row id first
+    q[401] = m[12]
+    q[402] = m[30_000]
+    q[7039] = m[40_000]
+    q[500] = 0
+    m[777] = 0
+    mem = _mem("f16", M, D)
+    for lo in range(0, M, 25_000):
+        mem.append(m[lo:lo + 25_000])
+    mem.reset_uncertified()
+    s, r = mem.topk(q, k)
+    redone = mem.uncertified_count
+    s_np, r_np = s.cpu().numpy(), r.cpu().numpy()
+    assert r_np[401, :3].tolist() == [12, 4095, 4096] and r_np[402, :2].tolist() == [30_000, 32_768]
+    assert r_np[7039, :2].tolist() == [40_000, 99_999]
+    s2, r2 = mem.topk(q, k, exact=True)
+    assert np.array_equal(r2.cpu().numpy(), r_np) and np.array_equal(s2.cpu().numpy(), s_np)
+    picks = np.unique(np.concatenate([np.arange(0, Q, 53), [401, 402, 500, 6911, 6912, 7000, 7039],
+                                      256 * np.arange(28) + 17 * (np.arange(28) % 15)]))
+    picks = picks[picks < Q]
+    want_r, want_s = _oracle_rows_parallel(_bits(q), _bits(m), k, "f16", picks)
+    assert np.array_equal(r_np[picks], want_r)
+    assert np.array_equal(s_np[picks], want_s)
+    assert redone <= 8, redone                 # the zero query ties with everything; nothing else may need the redo
+
+
+def test_gemm_class_scan_bf16_ring_ragged_bit_exact():
+    """GEMM-class scan on a wrapped RING of bf16 rows at D = 1024 with a ragged query count (600 = 2 full tiles + 88)
+    and a ragged row count (not a multiple of 256): every query against the exhaustive fp64 kernel, 64 against the C
+    oracle."""
+    rng = np.random.default_rng(1024)
+    D, M, Q, k = 1024, 140_100, 600, 20
+    extra = 3_000
+    hist = torch.tensor(rng.standard_normal((M + extra, D)), dtype=torch.float32).to(torch.bfloat16)
+    q = torch.tensor(rng.standard_normal((Q, D)), dtype=torch.float32).to(torch.bfloat16)
+    picks_m = rng.integers(extra, M + extra, 50)
+    q[:50] = (0.7 * hist[picks_m].float() + 0.3 * q[:50].float()).to(torch.bfloat16)
+    hist[extra + 90_000] = hist[extra + 40]
+    q[51] = hist[extra + 40]
+    mem = _mem("bf16", M, D, ring=True)
+    for lo in range(0, M + extra, 20_000):
+        mem.append(hist[lo:lo + 20_000])
+    mem.reset_uncertified()
+    s, r = mem.topk(q, k)
+    s_np, r_np = s.cpu().numpy(), r.cpu().numpy()
+    assert r_np[51, :2].tolist() == [extra + 40, extra + 90_000]
+    s2, r2 = mem.topk(q, k, exact=True)
+    assert np.array_equal(r2.cpu().numpy(), r_np) and np.array_equal(s2.cpu().numpy(), s_np)
+    picks = np.unique(np.concatenate([np.arange(0, Q, 11), [51, 511, 512, 599]]))
+    want_r, want_s = _oracle_rows_parallel(_bits(q), _bits(hist[extra:]), k, "bf16", picks)
+    want_r = np.where(want_r >= 0, want_r + extra, -1)
+    assert np.array_equal(r_np[picks], want_r)
+    assert np.array_equal(s_np[picks], want_s)
+    assert mem.uncertified_count <= 4
+
+
+def test_gemm_class_scan_tie_flood_marks_and_redoes():
+    """5,000 copies of one query's row (more candidates at or above the cut than a candidate buffer holds) and 300
+    copies of another row spread over every pass of the incremental cascade: the queries are marked - the mark of an
+    EARLY pass must survive the later ones - and redone exhaustively; all 640 queries equal the exhaustive kernel."""
+    rng = np.random.default_rng(5)
+    D, M, Q, k = 256, 300_000, 640, 10
+    m = torch.tensor(rng.standard_normal((M, D)), dtype=torch.float32).to(torch.float16)
+    q = torch.tensor(rng.standard_normal((Q, D)), dtype=torch.float32).to(torch.float16)
+    flood = rng.choice(np.arange(5_000, 30_000), 5000, replace=False)     # inside the second pass's rows
+    m[flood] = q[7].clone()
+    ties = rng.choice(np.setdiff1d(np.arange(0, M), flood), 300, replace=False)
+    m[ties] = m[M - 1].clone()
+    q[9] = m[M - 1]
+    mem = _mem("f16", M, D)
+    mem.append(m)
+    mem.reset_uncertified()
+    s, r = mem.topk(q, k)
+    assert 2 <= mem.uncertified_count <= 6
+    s2, r2 = mem.topk(q, k, exact=True)
+    assert np.array_equal(r2.cpu().numpy(), r.cpu().numpy()) and np.array_equal(s2.cpu().numpy(), s.cpu().numpy())
+    assert r[7].tolist() == sorted(flood.tolist())[:k]
+    want_r, want_s = cref.cosine_topk(_bits(q[[7, 9, 100]]), _bits(m), k, dtype="f16")
+    assert np.array_equal(r[[7, 9, 100]].cpu().numpy(), want_r) and np.array_equal(s[[7, 9, 100]].cpu().numpy(), want_s)
