@@ -151,3 +151,42 @@ def vit_forward_ref(spec: Dict, w: Dict[str, np.ndarray], pixels_chw, quant: Opt
         n = torch.sqrt((pooled * pooled).sum(dim=-1, keepdim=True))
         pooled = pooled / torch.clamp(n, min=1e-12)
     return q_(pooled, "out").numpy()
+
+
+@torch.no_grad()
+def vit_forward_fast(spec: Dict, w: Dict[str, np.ndarray], pixels_chw, l2_normalise: bool = True,
+                     tensors: Optional[Dict[str, torch.Tensor]] = None) -> np.ndarray:
+    """The SAME fp32 forward as ``vit_forward_ref(quant=None)`` written the way a CPU deployment would run it: weights
+    converted once (``tensors`` = ``fast_weights(w)``), ``torch.nn.functional`` linear / layer_norm / gelu / fused
+    scaled-dot-product attention on the whole batch.  bench.py times this as the best-effort CPU line (cpu_baseline
+    R2); tests/test_vit_oracle.py holds it to the restatement above at fp32 rounding."""
+    import torch.nn.functional as Fn
+    W = tensors if tensors is not None else fast_weights(w)
+    H, heads, L = spec["hidden"], spec["heads"], spec["layers"]
+    x = torch.as_tensor(np.asarray(pixels_chw), dtype=torch.float32)
+    B = x.shape[0]
+    tok = Fn.linear(patchify(x, spec["patch"]), W["patch_w"], W["patch_b"] if spec["patch_bias"] else None)
+    x = torch.cat([W["cls"].reshape(1, 1, H).expand(B, 1, H), tok], dim=1) + W["pos"].unsqueeze(0)
+    if spec["pre_ln"]:
+        x = Fn.layer_norm(x, (H,), W["pre_ln_g"], W["pre_ln_b"], spec["ln_eps"])
+    N = x.shape[1]
+    for l in range(L):
+        p = lambda n: W[f"l{l}.{n}"]
+        h = Fn.layer_norm(x, (H,), p("ln1_g"), p("ln1_b"), spec["ln_eps"])
+        qkv = Fn.linear(h, p("qkv_w"), p("qkv_b")).reshape(B, N, 3, heads, H // heads).permute(2, 0, 3, 1, 4)
+        ctx = Fn.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2])
+        x = x + Fn.linear(ctx.transpose(1, 2).reshape(B, N, H), p("proj_w"), p("proj_b"))
+        h = Fn.layer_norm(x, (H,), p("ln2_g"), p("ln2_b"), spec["ln_eps"])
+        a = Fn.linear(h, p("fc1_w"), p("fc1_b"))
+        a = Fn.gelu(a) if spec["act"] == "gelu" else a * torch.sigmoid(1.702 * a)
+        x = x + Fn.linear(a, p("fc2_w"), p("fc2_b"))
+    pooled = Fn.layer_norm(x[:, 0], (H,), W["ln_g"], W["ln_b"], spec["ln_eps"])
+    if spec.get("proj_dim", 0):
+        pooled = Fn.linear(pooled, W["proj_w"])
+    if l2_normalise:
+        pooled = pooled / torch.clamp(torch.sqrt((pooled * pooled).sum(dim=-1, keepdim=True)), min=1e-12)
+    return pooled.numpy()
+
+
+def fast_weights(w: Dict[str, np.ndarray]) -> Dict[str, torch.Tensor]:
+    return {k: torch.as_tensor(np.asarray(v), dtype=torch.float32).contiguous() for k, v in w.items()}

@@ -12,7 +12,7 @@ Keys the hot path honours (same names and defaults as the reference where it has
   embedder.top_k_chunk_with_batch_similarity = 3, embedder.top_k_similar_batch = 2 src/core/config.py:57-62
   retrieval.top_k = 5, top_k_chunks = 8, compression_threshold = 0.7               src/core/config.py:70-86
 New:
-  encoder: {arch, dtype, weights, seed, device, top_k}     which vision encoder stands where the remote VLM was
+  encoder: {arch, dtype, weights, seed, device, top_k, look_ahead_chunks}   which vision encoder stands where the remote VLM was
   memory:  {capacity, ring, dtype, snapshot}               the HBM-resident store that stands where Chunk.embedding was
 """
 from __future__ import annotations
@@ -27,6 +27,7 @@ ENCODER_DEFAULTS: Dict[str, Any] = {
     "seed": 42,              # seed of the synthetic weights (no checkpoint can be fetched offline)
     "device": 0,
     "top_k": 5,              # neighbours reported per frame in the output JSON (`similar`)
+    "look_ahead_chunks": 1,  # chunks encoded per encoder call (extractor.py: same neighbours and rows as 1, bit for bit)
 }
 MEMORY_DEFAULTS: Dict[str, Any] = {
     "capacity": 100_000,     # rows resident in HBM (the reference caps its read-back at 5000: pre_llm_injector.py:398)

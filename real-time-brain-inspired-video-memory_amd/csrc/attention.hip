@@ -119,10 +119,10 @@ __device__ __forceinline__ void attend_tile(const char *kl, const char *vl, type
 }
 
 // Long rows (577 tokens: 37 key tiles): the whole score row does not fit in registers next to the accumulators
-// (148 VGPRs of scores alone; the single-pass tile spilled ~100 registers), so the row is walked twice - pass 1
-// computes the scores and keeps only the row maximum, pass 2 recomputes them 32 keys at a time, exponentiates against
-// the known maximum and feeds P.V.  Exactly the full-row softmax (no online rescaling), +50 % QK^T MFMAs (the matrix
-// pipe has the room), no spills.
+// (148 VGPRs of scores alone; the single-pass tile spilled ~100 registers).  Two builds: the default ONLINE one
+// (attend_tile_pass2<..., true>: one walk over the keys, lazily raised reference) and, behind VIDMEM_ATTN_ONLINE=0,
+// the two-pass one - this pass 1 computes the scores and keeps only the row maximum, pass 2 recomputes them 32 keys
+// at a time against the known maximum (+50 % QK^T MFMAs, no rescaling).
 template <int DT, int NT, bool EXACT>
 __device__ __forceinline__ float attend_rowmax(const char *kl, typename vm_elem<DT>::vec8 qa,
                                                typename vm_elem<DT>::vec8 qb, int T, int lane) {
@@ -160,9 +160,9 @@ __device__ __forceinline__ float attend_rowmax(const char *kl, typename vm_elem<
     return mx;
 }
 
-// ONLINE: no first pass - the row maximum is tracked step by step and the running sums are rescaled (a wave-uniform
-// branch, taken only in the steps where some row's maximum grows).  Same softmax; the products exp2((s - m_t) c) *
-// exp2((m_t - m_final) c) differ from exp2((s - m_final) c) by fp32 roundings only.
+// ONLINE: no first pass - a reference value per row is raised step by step and the running sums are rescaled (a
+// wave-uniform branch, taken only in the steps where some row's scores break out of the reference's slack).  Same
+// softmax: exp2((s - m_ref) c) / sum of the same is shift-invariant; only fp32 / 16-bit roundings differ.
 template <int DT, int NT, bool EXACT, bool ONLINE = false>
 __device__ __forceinline__ void attend_tile_pass2(const char *kl, const char *vl, typename vm_elem<DT>::vec8 qa,
                                                   typename vm_elem<DT>::vec8 qb, float mx, int T, int lane,
@@ -175,7 +175,9 @@ __device__ __forceinline__ void attend_tile_pass2(const char *kl, const char *vl
     const int r16 = lane & 15, h = lane >> 4;
     const int tq = r16 >> 2, tp = r16 & 3;
     const float scale_log2e = 0.125f * 1.44269504088896340736f;
-    float run_m = ONLINE ? -1e30f : mx;  // running (ONLINE) or known row maximum
+    constexpr float ONLINE_SLACK = 6.0f;   // scores may exceed the reference by 2^6 in the exponent before a rescale
+    float run_m = ONLINE ? -1e30f : mx;    // reference (ONLINE: lazily raised) or known row maximum
+    float run_hi = -1e30f;                 // ONLINE: run_m + the slack, in score units
     float neg_mxc = -run_m * scale_log2e;
     const f32x2 c2 = {scale_log2e, scale_log2e};
     f32x2 n2 = {neg_mxc, neg_mxc};
@@ -223,17 +225,26 @@ __device__ __forceinline__ void attend_tile_pass2(const char *kl, const char *vl
             for (int j = 0; j < 4; ++j) a[1][j] = ((2 * ks + 1) * 16 + 4 * h + j < T) ? a[1][j] : -INFINITY;
         }
         if (ONLINE) {
-            float lm = fmaxf(fmaxf(fmaxf(a[0][0], a[0][1]), fmaxf(a[0][2], a[0][3])),
-                             fmaxf(fmaxf(a[1][0], a[1][1]), fmaxf(a[1][2], a[1][3])));
-            lm = fmaxf(lm, __shfl_xor(lm, 16, 64));
-            lm = fmaxf(lm, __shfl_xor(lm, 32, 64));
-            if (__ballot(lm > run_m) != 0ull) {  // wave-uniform: some query row of this tile has a new maximum
-                const float m_new = fmaxf(run_m, lm);
-                const float f = __builtin_amdgcn_exp2f((run_m - m_new) * scale_log2e);  // 1 where nothing changed
+            // LAZY reference: run_m is not the running maximum but a reference the scores may exceed by up to
+            // ONLINE_SLACK (in units of the exponent, i.e. probabilities up to 2^ONLINE_SLACK before the final division:
+            // harmless in fp32 sums and in a 16-bit P, whose relative precision does not depend on its magnitude).
+            // The common step therefore needs no cross-lane traffic at all: every lane tests its OWN eight scores
+            // against the shared reference (one ballot); only when some score breaks out - the first step, and the few
+            // later ones where the row maximum grows by more than the slack - are the two shuffles, the rescale of
+            // the sums and the new reference paid.  (With the reference tied to the exact running maximum every step
+            // carried a dependent chain max -> shuffle -> max -> shuffle -> ballot of ~300 cycles.)
+            const float lm_own = fmaxf(fmaxf(fmaxf(a[0][0], a[0][1]), fmaxf(a[0][2], a[0][3])),
+                                       fmaxf(fmaxf(a[1][0], a[1][1]), fmaxf(a[1][2], a[1][3])));
+            if (__ballot(lm_own > run_hi) != 0ull) {  // wave-uniform
+                float lm = fmaxf(lm_own, __shfl_xor(lm_own, 16, 64));
+                lm = fmaxf(lm, __shfl_xor(lm, 32, 64));
+                const float m_new = fmaxf(run_m, lm);  // rows whose scores stayed below keep their reference (f = 1)
+                const float f = __builtin_amdgcn_exp2f((run_m - m_new) * scale_log2e);
                 sum2 *= f32x2{f, f};
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) o[dt] *= f32x4{f, f, f, f};
                 run_m = m_new;
+                run_hi = run_m + ONLINE_SLACK / scale_log2e;
                 neg_mxc = -run_m * scale_log2e;
                 n2 = f32x2{neg_mxc, neg_mxc};
             }
@@ -345,7 +356,8 @@ __global__ void __launch_bounds__(NW * 64, 1)
 template <int DT, int NT, bool EXACT>
 int launch_long(vm_ctx *ctx, const uint16_t *qkv, uint16_t *out, int B, int T, int heads, hipStream_t st, int qt_lim) {
     const size_t lds = (size_t)NT * 16 * 128 * 2;
-    // 16 waves (4 per SIMD; the kernel needs ~80 VGPRs): 21.1 ms vs 27.0 ms with 8 waves per 256-frame CLIP-L pass
+    // 16 waves (4 per SIMD; the kernel needs ~80 VGPRs).  Measured on the two-pass build: 21.1 ms vs 27.0 ms with 8
+    // waves per 256-frame CLIP-L pass
     static int online_env = -1;
     if (online_env < 0) {
         const char *e = getenv("VIDMEM_ATTN_ONLINE");

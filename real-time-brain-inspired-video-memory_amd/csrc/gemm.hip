@@ -18,6 +18,7 @@
 //                   most CUs idle (small batches).
 #include "vm_internal.h"
 #include "vm_kernels.h"
+#include "gemm_guard.h"
 
 namespace {
 
@@ -53,6 +54,13 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
     r.x = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t.x));
     r.y = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t.y));
     return x * r;
+}
+
+// EPI_DELTA16 stores a bf16 encoder's residual-branch outputs as fp16 (vm_kernels.h): values beyond fp16's range - the
+// outlier activations a bf16 checkpoint may have been chosen for - saturate at +-65504 instead of becoming inf (which
+// the LayerNorm behind it would turn into a NaN row).  v_med3_f32: one instruction per element, bf16 encoders only.
+__device__ __forceinline__ f32x2 sat_f16(f32x2 v) {
+    return f32x2{__builtin_amdgcn_fmed3f(v.x, -65504.0f, 65504.0f), __builtin_amdgcn_fmed3f(v.y, -65504.0f, 65504.0f)};
 }
 
 // Element index of out16[t, f]: row-major [M, ldo], or head-major [N/64][M][64] (each 64-feature head a contiguous
@@ -107,6 +115,10 @@ __device__ __forceinline__ void epilogue_row(const GemmArgs &g, const f32x4 (&a)
             if (EPI == EPI_QGELU16) {
                 v01 = f32x2{quick_gelu(v01.x), quick_gelu(v01.y)};
                 v23 = f32x2{quick_gelu(v23.x), quick_gelu(v23.y)};
+            }
+            if (EPI == EPI_DELTA16) {
+                v01 = sat_f16(v01);
+                v23 = sat_f16(v23);
             }
             store_out16(g, g.out16 + out16_index(g, t, fbase + 16 * i),
                         make_uint2(E::pack2(v01.x, v01.y), E::pack2(v23.x, v23.y)));
@@ -200,6 +212,10 @@ __device__ __forceinline__ void epilogue16(const GemmArgs &g, const f32x4 (&acc)
             if (EPI == EPI_QGELU16) {
                 v01 = f32x2{quick_gelu(v01.x), quick_gelu(v01.y)};
                 v23 = f32x2{quick_gelu(v23.x), quick_gelu(v23.y)};
+            }
+            if (EPI == EPI_DELTA16) {
+                v01 = sat_f16(v01);
+                v23 = sat_f16(v23);
             }
             pk[i] = u32x2{EO::pack2(v01.x, v01.y), EO::pack2(v23.x, v23.y)};  // v_cvt_pk_*
         }
@@ -436,18 +452,35 @@ __global__ void __launch_bounds__(512, 1) gemm256p_kernel(GemmArgs g) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, h = lane >> 4;
     const int tiles_n = g.N >> 8;
-    const int ntiles = ((g.M + 255) >> 8) * tiles_n;
+    const int panels = (g.M + 255) >> 8;
+    const int ntiles = panels * tiles_n;
     const int vbid = xcd_remap(blockIdx.x, gridDim.x);
     const int wr = wave >> 2, wc = wave & 3;
     const int K = g.K, M = g.M;
     const int nk = K / BK;
+    // Tile order.  Tiles are dealt to the workgroups in rounds of gridDim.x, 32 consecutive ones to an XCD.  With the
+    // feature tiles of a token panel consecutive (fgroup == tiles_n) an XCD touches EVERY weight tile in every round:
+    // weights larger than its 4 MiB L2 (FC1: 4.7 MB, QKV: 3.5 MB beside the activation stream) are re-fetched from the
+    // Infinity Cache once per round (PMC, round 2: FC1 604 MB of 1,316 MB fabric traffic per launch).  So the feature
+    // tiles go in GROUPS of `fgroup` whose weights fit an L2: all token panels against group 0, then all against group
+    // 1, ...: the weights of a group come in once per XCD, the activations are streamed once per group instead.
+    const int fgroup = g.fgroup > 0 && g.fgroup < tiles_n ? g.fgroup : tiles_n;
+    auto tile_coords = [&](int tile, int &tm, int &tn) {
+        const int per_group = panels * fgroup;           // tiles of a full group (only the last one may be smaller)
+        const int grp = tile / per_group;
+        const int r = tile - grp * per_group;
+        int gsz = tiles_n - grp * fgroup;
+        if (gsz > fgroup) gsz = fgroup;
+        tm = r / gsz;
+        tn = grp * fgroup + (r - tm * gsz);
+    };
 
     // Staging by BUFFER loads to LDS (buffer_load_dwordx4 ... offen lds): the per-lane part of a source address is a
-    // 32-bit byte offset that never changes (row of the lane inside the tile, swizzled chunk), the tile origin and the
-    // K-tile are a wave-uniform SGPR offset.  Against global_load_lds with 64-bit per-lane pointers this drops eight
-    // 64-bit pointers (16 VGPRs) and the per-tile pointer arithmetic (time: equal within 1 %, the projection GEMM 5 %
-    // faster).  Token rows past M need no clamp: they lie past the descriptor's num_records, the range check returns
-    // zeros, and their outputs are never stored.
+    // 32-bit byte offset that never changes (row of the lane inside the tile, swizzled chunk), the tile origin sits in
+    // the descriptor's base and the K-tile in the wave-uniform soffset.  Against global_load_lds with 64-bit per-lane
+    // pointers this drops eight 64-bit pointers (16 VGPRs) and the per-tile pointer arithmetic (time: equal within
+    // 1 %, the projection GEMM 5 % faster).  Token rows past M need no clamp: their per-lane offset lies past the
+    // tile descriptor's num_records, the range check returns zeros, and their outputs are never stored.
     const int srow = lane >> 3, scp = lane & 7;
     const int chunk = scp ^ srow;
     unsigned voff_w[2], voff_x[2];   // byte offsets of this lane's 16 bytes inside the W / X tile, region *a0* / *b0*
@@ -462,28 +495,36 @@ __global__ void __launch_bounds__(512, 1) gemm256p_kernel(GemmArgs g) {
         lds_wa0[u] = wrow0 * 128;
         lds_xb0[u] = 2 * HALF_BYTES + xrow0 * 128;
     }
-    const __amdgpu_buffer_rsrc_t rs_w =
-        __builtin_amdgcn_make_buffer_rsrc((void *)g.W, 0, (int)((size_t)g.N * K * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_x =
-        __builtin_amdgcn_make_buffer_rsrc((void *)g.X, 0, (int)((size_t)M * g.ldx * 2), 0x00020000);
-    unsigned so_w = 0, so_x = 0;   // byte offset of the current tile's origin (row f0 of W, row t0 of X), wave-uniform
+    // One descriptor per operand and TILE: base = the tile's first row, num_records = the bytes of the tile's rows that
+    // exist (gemm_guard.h bounds them below 2^31), so (a) nothing here is a 32-bit offset from the start of a tensor -
+    // any M, any row stride - and (b) a row past M is out of range by its PER-LANE offset alone: the wave-uniform
+    // soffset only ever carries the K-tile (128 B x kt, inside the row), whatever the hardware's range check makes of
+    // an soffset.
+    __amdgpu_buffer_rsrc_t rs_w, rs_x;
     const unsigned w64 = (unsigned)(64 * K * 2), x32 = (unsigned)(32 * g.ldx * 2);   // region *1 = region *0 + 64 / 32 rows
     auto set_sources = [&](int tile) {
-        const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-        so_w = (ABL & 64) ? 0u : (unsigned)((tn << 8) * K * 2);                      // ablation: every tile reads W tile 0
-        so_x = (ABL & 32) ? 0u : (unsigned)(((size_t)(tm << 8) * g.ldx) * 2);        // ablation: ... token panel 0
+        int tm, tn;
+        tile_coords(tile, tm, tn);
+        const int f0s = (ABL & 64) ? 0 : (tn << 8);     // ablation: every tile reads W tile 0
+        const int t0s = (ABL & 32) ? 0 : (tm << 8);     // ablation: ... token panel 0
+        int vt = M - t0s;
+        if (vt > 256) vt = 256;
+        rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)(g.W + (size_t)f0s * K), 0, 256 * K * 2, 0x00020000);
+        // the last existing row ends K elements in, not ldx (a strided view's allocation may stop there)
+        rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)(g.X + (size_t)t0s * g.ldx), 0,
+                                                 (int)(((size_t)(vt - 1) * g.ldx + K) * 2), 0x00020000);
     };
-    auto dma2 = [&](const __amdgpu_buffer_rsrc_t rs, const unsigned (&voff)[2], unsigned soff, const int (&dst)[2],
-                    int extra, int buf) {
+    auto dma2 = [&](const __amdgpu_buffer_rsrc_t rs, const unsigned (&voff)[2], unsigned vextra, unsigned soff,
+                    const int (&dst)[2], int extra, int buf) {
 #pragma unroll
         for (int u = 0; u < 2; ++u)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(smem + buf * 4 * HALF_BYTES + dst[u] + extra), 16,
-                                                     voff[u], soff, 0, 0);
+                                                     voff[u] + vextra, soff, 0, 0);
     };
-    auto stage_Wa0 = [&](int kt, int buf) { dma2(rs_w, voff_w, so_w + kt * (BK * 2), lds_wa0, 0, buf); };
-    auto stage_Wa1 = [&](int kt, int buf) { dma2(rs_w, voff_w, so_w + w64 + kt * (BK * 2), lds_wa0, 64 * 128, buf); };
-    auto stage_Xb0 = [&](int kt, int buf) { dma2(rs_x, voff_x, so_x + kt * (BK * 2), lds_xb0, 0, buf); };
-    auto stage_Xb1 = [&](int kt, int buf) { dma2(rs_x, voff_x, so_x + x32 + kt * (BK * 2), lds_xb0, 32 * 128, buf); };
+    auto stage_Wa0 = [&](int kt, int buf) { dma2(rs_w, voff_w, 0u, kt * (BK * 2), lds_wa0, 0, buf); };
+    auto stage_Wa1 = [&](int kt, int buf) { dma2(rs_w, voff_w, w64, kt * (BK * 2), lds_wa0, 64 * 128, buf); };
+    auto stage_Xb0 = [&](int kt, int buf) { dma2(rs_x, voff_x, 0u, kt * (BK * 2), lds_xb0, 0, buf); };
+    auto stage_Xb1 = [&](int kt, int buf) { dma2(rs_x, voff_x, x32, kt * (BK * 2), lds_xb0, 32 * 128, buf); };
 
     const int sw0 = ((h ^ (r16 & 7)) << 4), sw1 = (((h + 4) ^ (r16 & 7)) << 4);
     const int a_base = (wr * 128 + r16) * 128;
@@ -652,7 +693,8 @@ __global__ void __launch_bounds__(512, 1) gemm256p_kernel(GemmArgs g) {
         // until phase 2 of the next K-tile) so that every store instruction writes 4 rows x 256 contiguous bytes
         // instead of 16 rows x 32 bytes.
         {
-            const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+            int tm, tn;
+            tile_coords(tile, tm, tn);
             const int t0 = tm << 8, f0 = tn << 8;
             if (ABL & 16) {
 #pragma unroll
@@ -678,7 +720,8 @@ __global__ void __launch_bounds__(512, 1) gemm256p_kernel(GemmArgs g) {
         if (wr == 1) VM_BAR();
         if (!has_next) break;
         {   // how many stores did this wave's epilogue leave in the pipe?  exact only for a full 16-bit tile
-            const int tm_done = tile / tiles_n;
+            int tm_done, tn_done;
+            tile_coords(tile, tm_done, tn_done);
             const bool full = ((tm_done << 8) + 256 <= M) && OUT16 && !(ABL & 24);
             ep = full ? 1 : 2;
         }
@@ -791,7 +834,8 @@ int launch_epi(vm_ctx *ctx, const GemmArgs &g, hipStream_t st) {
     }
     const int variant = g_variant ? g_variant : env_variant;
     const int tiles256 = ((g.M + 255) / 256) * (g.N / 256);
-    const bool big_ok = g.N % 256 == 0;
+    // the 256 x 256 kernels address a tile through 32-bit byte offsets inside per-tile descriptors (gemm_guard.h)
+    const bool big_ok = g.N % 256 == 0 && vm_gemm256_tile_addressable(g.K, g.ldx);
     // a 256^2 grid must give (nearly) every CU a tile; below that the 128^2 kernel fills the chip better
     const bool use256 = (variant == 2 || variant == 3) ? big_ok : (variant == 1 ? false : (big_ok && tiles256 * 10 >= ctx->num_cus * 8));
 #ifdef VM_GEMM_ABLATE
@@ -897,5 +941,25 @@ int vm_gemm(vm_ctx *ctx, int dtype, const GemmArgs &g, int epi, hipStream_t st) 
     a.stream_out = (size_t)g.M * g.N * 2 > ((size_t)32 << 20);  // more than the 8 x 4 MiB of L2
     if (a.hm_rows <= 0) a.hm_rows = g.M;
     if (a.hm_stride <= 0) a.hm_stride = 1;
+    {   // feature-tile groups of the persistent 256 x 256 kernel (gemm256p_kernel, "Tile order")
+        static long budget = -1;
+        if (budget < 0) {
+            const char *e = getenv("VIDMEM_GEMM_WGROUP_KB");   // weight bytes an XCD's L2 keeps beside the streams; 0 = off
+            budget = e ? atol(e) * 1024 : 2560 * 1024;
+        }
+        a.fgroup = 0;
+        const int tiles_n = g.N / 256;
+        const long wtile = 256L * g.K * 2, wall = wtile * tiles_n;
+        if (budget > 0 && g.N % 256 == 0 && wall > budget && wtile <= budget) {
+            const int ngroups = (int)((wall + budget - 1) / budget);
+            const int fg = (tiles_n + ngroups - 1) / ngroups;
+            const int ng = (tiles_n + fg - 1) / fg;
+            // worth it only when re-streaming the activations costs less than re-fetching the weights every round
+            const double x_extra = (double)(ng - 1) * g.M * g.K * 2;
+            const double rounds = (double)((g.M + 255) / 256) * tiles_n / (ctx ? ctx->num_cus : 256);
+            const double w_refetch = rounds * 8.0 * wall;
+            if (x_extra < w_refetch) a.fgroup = fg;
+        }
+    }
     return dtype == VM_F16 ? launch<VM_F16>(ctx, a, epi, st) : launch<VM_BF16>(ctx, a, epi, st);
 }

@@ -29,6 +29,7 @@ struct GemmArgs {
     int hm_rows, hm_stride;  // head-major only: rows per head block (0 = M) and the block row of GEMM row t = t * hm_stride
                              // (0 = 1): lets a GEMM over the CLS rows alone write into the all-rows q blocks
     int stream_out;     // set by vm_gemm: the 16-bit output is larger than L2 and leaves with the non-temporal policy
+    int fgroup;         // set by vm_gemm: feature tiles per group of the persistent kernel's tile order (0 = all)
 };
 
 int vm_gemm(vm_ctx *ctx, int dtype, const GemmArgs &g, int epi, hipStream_t st);

@@ -148,11 +148,12 @@ class FrameEmbeddingExtractor:
         (module docstring: the one deliberate deviation)."""
         return [f for f in (src.read(i) for i in indices) if f is not None]
 
-    def _stage(self, frames: List[np.ndarray]):
-        """Start the H2D copy of a chunk (ingest.FrameStager: pinned slot + copy stream); the stager is sized on the
-        first chunk and rebuilt if the frame size changes."""
+    def _stage(self, frames: List[np.ndarray], group_chunks: int = 1):
+        """Start the H2D copy of a group of chunks (ingest.FrameStager: pinned slot + copy stream); the stager is sized
+        on the first group and rebuilt if the frame size changes."""
         h, w = frames[0].shape[:2]
-        cap = max(len(frames), int(cfgmod.section(self.config, "video", cfgmod.VIDEO_DEFAULTS).frames_per_chunk))
+        fpc = int(cfgmod.section(self.config, "video", cfgmod.VIDEO_DEFAULTS).frames_per_chunk)
+        cap = max(len(frames), fpc * max(1, group_chunks))
         if self._stager is None or self._stager.shape[1:3] != (h, w) or self._stager.shape[0] < len(frames):
             factory = self._stager_factory
             if factory is None:
@@ -170,47 +171,99 @@ class FrameEmbeddingExtractor:
             total_chunks, plan = chunk_plan(fps, total_frames, video_cfg.chunk_size_seconds,
                                             video_cfg.frames_per_chunk)
             results = []
+            # Look-ahead groups (config.encoder.look_ahead_chunks, default 1 = the reference's one chunk at a time,
+            # :44-74): the frames of N consecutive chunks go through ONE encoder call - the encoder fills the chip only
+            # from a few hundred frames up - and then every chunk of the group, in chunk order, gets its own top-k
+            # against the memory as it stands (chunks < i, the group's earlier chunks included) followed by its own
+            # append: the same neighbours and the same rows as N = 1, bit for bit (an embedding does not depend on the
+            # batch it was computed in: tests/test_encoder_gpu.py::test_bench_size_batches...).  Results are read
+            # back once per group, AFTER the next group's launches are queued, so the GPU never waits for the host.
+            L = max(1, int(cfgmod.section(self.config, "encoder", cfgmod.ENCODER_DEFAULTS).look_ahead_chunks))
+            groups = [plan[i:i + L] for i in range(0, len(plan), L)]
+            dev = self.encoder.device
 
-            def read_and_stage(pi):
-                """Host side of chunk pi: frame reads + pinned staging + start of the H2D copy (None: no frames)."""
-                if pi >= len(plan):
+            def read_and_stage(gi):
+                """Host side of group gi: frame reads + pinned staging + start of the H2D copy."""
+                if gi >= len(groups):
                     return None
-                frames = self._read_chunk(src, plan[pi][3])
-                return (len(frames), self._stage(frames)) if frames else None
+                counts, frames = [], []
+                for (_ci, _s, _e, indices, _t) in groups[gi]:
+                    fr = self._read_chunk(src, indices)
+                    counts.append(len(fr))
+                    frames += fr
+                return counts, (self._stage(frames, L) if frames else None)
+
+            def finish(pend):
+                """Read one group's neighbours back (its event has fired long before the host gets here)."""
+                chunks, host_s, host_r, ev, t_start = pend
+                if ev is not None:
+                    ev.synchronize()
+                group_time = time.perf_counter() - t_start
+                live = [c for c in chunks if c["nframes"]]
+                off = 0
+                for c in live:
+                    similar = []
+                    if c["searched"]:
+                        n = c["nframes"]
+                        for s_row, r_row in zip(host_s[off:off + n].tolist(), host_r[off:off + n].tolist()):
+                            similar.append([(self.memory.id_of(r), float(s)) for s, r in zip(s_row, r_row) if r >= 0])
+                        off += n
+                    chunk_time = group_time / len(live)
+                    results.append({
+                        "time": c["time"],
+                        "content": f"[{c['nframes']} frame embeddings]",
+                        "chunk_idx": c["chunk_idx"],
+                        "processing_time": chunk_time,
+                        "embedding_rows": list(range(c["first"], c["first"] + c["nframes"])),
+                        "similar": similar,
+                    })
+                    self.timings.append((f"chunk_{c['chunk_idx']}", chunk_time))
+                    self.metrics.record_timing(f"chunk_{c['chunk_idx']}", "vlm_inference", chunk_time)   # key of :73
 
             staged = read_and_stage(0)
-            for pi, (chunk_idx, start, end, indices, time_str) in enumerate(plan):
-                chunk_start = time.perf_counter()
-                current, emb = staged, None
-                if current is not None:
-                    nframes, ticket = current
-                    emb = self.encoder.embed_frames(self._stager.get(ticket))   # asynchronous launches
+            pending = None
+            for gi, grp in enumerate(groups):
+                t_start = time.perf_counter()
+                counts, ticket = staged
+                emb_all = None
+                if ticket is not None:
+                    emb_all = self.encoder.embed_frames(self._stager.get(ticket))   # asynchronous launches
                     self._stager.done(ticket)
-                # while the GPU encodes chunk pi, the host reads chunk pi+1 and its frames cross PCIe
-                staged = read_and_stage(pi + 1)
-                if emb is None:
-                    continue
-                similar = []
-                if self.memory.searchable and self.top_k > 0:
-                    scores, rows = self.memory.topk(emb, self.top_k)
-                    for s_row, r_row in zip(scores.cpu().tolist(), rows.cpu().tolist()):
-                        similar.append([(self.memory.id_of(r), float(s)) for s, r in zip(s_row, r_row) if r >= 0])
-                ids = [f"{run_id}_{chunk_idx}_{i}" for i in range(nframes)]  # pre_llm_injector.py:91 id scheme
-                created = time.strftime("%Y-%m-%dT%H:%M:%S+00:00", time.gmtime())   # Chunk.created_at of the export
-                first = self.memory.append(emb, ids=ids, meta=[{"time": time_str, "content": None,
-                                                                "batch_id": chunk_idx, "created_at": created}] * nframes)
-                torch.cuda.synchronize(self.encoder.device)
-                chunk_time = time.perf_counter() - chunk_start
-                results.append({
-                    "time": time_str,
-                    "content": f"[{nframes} frame embeddings]",
-                    "chunk_idx": chunk_idx,
-                    "processing_time": chunk_time,
-                    "embedding_rows": list(range(first, first + nframes)),
-                    "similar": similar,
-                })
-                self.timings.append((f"chunk_{chunk_idx}", chunk_time))
-                self.metrics.record_timing(f"chunk_{chunk_idx}", "vlm_inference", chunk_time)   # key of :73
+                # while the GPU encodes group gi, the host reads group gi+1 and its frames cross PCIe
+                staged = read_and_stage(gi + 1)
+                chunks, dev_s, dev_r, off = [], [], [], 0
+                for (chunk_idx, start, end, indices, time_str), nframes in zip(grp, counts):
+                    c = {"chunk_idx": chunk_idx, "time": time_str, "nframes": nframes, "searched": False, "first": 0}
+                    chunks.append(c)
+                    if not nframes:
+                        continue
+                    emb = emb_all[off:off + nframes]
+                    off += nframes
+                    if self.memory.searchable and self.top_k > 0:
+                        scores, rows = self.memory.topk(emb, self.top_k)
+                        dev_s.append(scores)
+                        dev_r.append(rows)
+                        c["searched"] = True
+                    ids = [f"{run_id}_{chunk_idx}_{i}" for i in range(nframes)]  # pre_llm_injector.py:91 id scheme
+                    created = time.strftime("%Y-%m-%dT%H:%M:%S+00:00", time.gmtime())   # Chunk.created_at of the export
+                    c["first"] = self.memory.append(emb, ids=ids, meta=[{"time": time_str, "content": None,
+                                                                         "batch_id": chunk_idx,
+                                                                         "created_at": created}] * nframes)
+                host_s = host_r = ev = None
+                if dev_s:
+                    cat_s, cat_r = torch.cat(dev_s), torch.cat(dev_r)
+                    host_s = torch.empty(cat_s.shape, dtype=cat_s.dtype).pin_memory()
+                    host_r = torch.empty(cat_r.shape, dtype=cat_r.dtype).pin_memory()
+                    host_s.copy_(cat_s, non_blocking=True)
+                    host_r.copy_(cat_r, non_blocking=True)
+                if emb_all is not None and emb_all.is_cuda:   # (a host stand-in for the encoder in the CPU tests: no event)
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream(dev))
+                if pending is not None:
+                    finish(pending)
+                pending = (chunks, host_s, host_r, ev, t_start)
+            if pending is not None:
+                finish(pending)
             output_data = {
                 "metadata": {"run_id": run_id, "video_path": video_path, "total_chunks": total_chunks,
                              "config": cfgmod.config_dict(self.config)},

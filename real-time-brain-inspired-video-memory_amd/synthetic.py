@@ -45,12 +45,23 @@ def encoder_weight_shapes(spec: Dict) -> Dict[str, tuple]:
     return shapes
 
 
-def encoder_weights(spec: Dict, seed: int = 42, std: float = 0.02) -> Dict[str, np.ndarray]:
-    """fp32 master weights: linear/conv/cls/pos/bias ~ N(0, std^2); LayerNorm gamma = 1 + N(0, std^2)."""
+def encoder_weights(spec: Dict, seed: int = 42, std: float = 0.02, tail: str = "normal") -> Dict[str, np.ndarray]:
+    """fp32 master weights: linear/conv/cls/pos/bias ~ N(0, std^2); LayerNorm gamma = 1 + N(0, std^2).
+    tail="heavy": the same variances from a Student-t with 4 degrees of freedom (excess kurtosis: single weights at
+    6-10 sigma), plus six "outlier" hidden channels whose LayerNorm gains are 6x - the heavy-tailed weight AND
+    activation statistics trained vision transformers show, which a 16-bit storage format is most sensitive to."""
     out = {}
+    heavy = tail == "heavy"
     for name, shape in encoder_weight_shapes(spec).items():
         is_gamma = name.endswith("_g")
-        out[name] = normal(seed, name, shape, std=std, mean=1.0 if is_gamma else 0.0)
+        if heavy and not is_gamma:
+            t = _gen(seed, name).standard_t(4.0, size=shape).astype(np.float32) * np.float32(std / np.sqrt(2.0))
+            out[name] = t
+        else:
+            out[name] = normal(seed, name, shape, std=std, mean=1.0 if is_gamma else 0.0)
+        if heavy and is_gamma:
+            ch = _gen(seed, "outlier_channels").choice(shape[0], size=6, replace=False)
+            out[name][ch] *= np.float32(6.0)
     if not spec["patch_bias"]:
         out["patch_b"] = np.zeros_like(out["patch_b"])
     return out

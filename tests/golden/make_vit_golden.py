@@ -94,35 +94,54 @@ def _hf_clip(spec, w):
 
 
 CASES = [
-    # name, spec, weight seed, weight std, n frames
-    ("tiny_vit", V.tiny_spec(), 42, 0.2, 3),
+    # name, spec, weight seed, weight std, n frames, weight distribution (synthetic.encoder_weights tail=)
+    ("tiny_vit", V.tiny_spec(), 42, 0.2, 3, "normal"),
     ("tiny_clip", V.tiny_spec(act="quick_gelu", pre_ln=True, patch_bias=False, ln_eps=1e-5, image=28, patch=7),
-     43, 0.2, 3),
-    ("vit_b16_224", V.VIT_B16_224, 42, 0.02, 2),
-    ("clip_l14_336", V.CLIP_L14_336, 42, 0.02, 1),
+     43, 0.2, 3, "normal"),
+    ("vit_b16_224", V.VIT_B16_224, 42, 0.02, 8, "normal"),
+    ("vit_b16_224_heavy", V.VIT_B16_224, 1789, 0.02, 8, "heavy"),
+    ("clip_l14_336", V.CLIP_L14_336, 42, 0.02, 4, "normal"),
+    ("clip_l14_336_heavy", V.CLIP_L14_336, 1848, 0.02, 4, "heavy"),
 ]
+SPEC_OF = {name: spec for name, spec, *_ in CASES}
 
 
-def main():
-    out = {}
+def main(only=None):
+    path = os.path.join(ROOT, "tests", "golden", "vit_golden.npz")
+    out = dict(np.load(path)) if (only and os.path.exists(path)) else {}
     with torch.no_grad():
-        for name, spec, seed, std, n in CASES:
-            w = syn.encoder_weights(spec, seed=seed, std=std)
-            px = syn.normal(1000 + seed, "pixels_" + name, (n, 3, spec["image"], spec["image"]))
+        for name, spec, seed, std, n, tail in CASES:
+            if only and name not in only:
+                continue
+            w = syn.encoder_weights(spec, seed=seed, std=std, tail=tail)
+            px = syn.normal(1000 + seed, "pixels_" + name.replace("_heavy", ""), (n, 3, spec["image"], spec["image"]))
             hf = (_hf_clip if spec["pre_ln"] else _hf_vit)(spec, w)
             want = hf(px)
             got = V.vit_forward_ref(spec, w, px, quant=None, l2_normalise=False)
             err = np.abs(want - got).max() / np.abs(want).max()
-            print(f"{name}: oracle vs transformers max rel err {err:.2e}")
+            print(f"{name}: oracle vs transformers max rel err {err:.2e}", flush=True)
             assert err < 2e-5, err
+            fast = V.vit_forward_fast(spec, w, px, l2_normalise=False)
+            errf = np.abs(want - fast).max() / np.abs(want).max()
+            print(f"{name}: functional (bench cpu_baseline) forward vs transformers max rel err {errf:.2e}", flush=True)
+            assert errf < 2e-5, errf
             out[name + "/fp32"] = V.vit_forward_ref(spec, w, px, quant=None)
             out[name + "/f16"] = V.vit_forward_ref(spec, w, px, quant="f16")
             out[name + "/bf16"] = V.vit_forward_ref(spec, w, px, quant="bf16")
+            # what NO implementation with 16-bit matrix operands can beat: only the operands rounded, per frame
+            for dt in ("f16", "bf16"):
+                fl = V.vit_forward_ref(spec, w, px, quant={p: dt for p in V.OPERAND_POINTS})
+                d = fl.astype(np.float64) - out[name + "/fp32"].astype(np.float64)
+                out[name + f"/floor_{dt}"] = np.concatenate([
+                    [np.linalg.norm(d) / np.linalg.norm(out[name + "/fp32"].astype(np.float64))],
+                    np.linalg.norm(d, axis=1) / np.linalg.norm(out[name + "/fp32"].astype(np.float64), axis=1)])
+                print(f"{name}: operand-only {dt} floor, batch {out[name + f'/floor_{dt}'][0]:.2e}, worst frame "
+                      f"{out[name + f'/floor_{dt}'][1:].max():.2e}", flush=True)
             out[name + "/seed_std_n"] = np.array([seed, std, n], dtype=np.float64)
-    path = os.path.join(ROOT, "tests", "golden", "vit_golden.npz")
+            out[name + "/tail"] = np.array([1.0 if tail == "heavy" else 0.0])
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")
 
 
 if __name__ == "__main__":
-    main()
+    main(set(sys.argv[1:]) or None)

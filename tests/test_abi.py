@@ -67,3 +67,35 @@ def test_product_package_never_imports_the_oracle():
                 assert "oracle" not in src.replace("the oracle", "").replace("oracle's", "").replace(
                     "as the oracle", "").replace("The oracle", "") or "import" not in src.split("oracle")[0][-40:], f
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f
+
+
+def test_gemm_tile_guard(tmp_path):
+    """csrc/gemm_guard.h: the 256 x 256 GEMM kernels address a tile through 32-bit byte offsets inside a per-tile buffer
+    descriptor; shapes whose tile would not fit below 2^31 bytes must be refused (they take the 128 x 128 kernel with
+    64-bit pointers).  Host-only: compiled with g++, no HIP."""
+    src = tmp_path / "guard.cpp"
+    src.write_text(r'''
+#include "gemm_guard.h"
+#include <cstdio>
+int main() {
+    struct { long long K, ldx; bool want; } c[] = {
+        {768, 768, true}, {3072, 3072, true}, {4096, 4096, true},
+        {768, 197LL * 768, true},                 // CLS rows addressed in place: row stride = one frame of tokens
+        {1024, 577LL * 1024, true},
+        {64, (1LL << 23) + 64, false},            // 255 rows x 16 MB stride: past 2^31
+        {(1LL << 22), (1LL << 22), false},        // 256 weight rows x 8 MB
+        {768, 512, false}, {0, 768, false},       // stride below the row length / empty rows
+    };
+    int bad = 0;
+    for (auto &t : c) if (vm_gemm256_tile_addressable(t.K, t.ldx) != t.want) { std::printf("K=%lld ldx=%lld\n", t.K, t.ldx); ++bad; }
+    // the limit itself: 255 * ldx + K elements of 2 bytes must stay below 2^31 bytes
+    long long ldx = ((1LL << 30) - 768) / 255;
+    if (!vm_gemm256_tile_addressable(768, ldx)) ++bad;
+    if (vm_gemm256_tile_addressable(768, ldx + 4)) ++bad;
+    return bad;
+}
+''')
+    exe = tmp_path / "guard"
+    inc = os.path.join(ROOT, "real-time-brain-inspired-video-memory_amd", "csrc")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", inc, str(src), "-o", str(exe)])
+    assert subprocess.call([str(exe)]) == 0

@@ -82,6 +82,40 @@ def test_extractor_from_config_alone_and_neighbours_against_the_oracle(tmp_path,
     assert ex2.memory.id_of(7) == f"{run_id}_1_1"
 
 
+def test_look_ahead_groups_change_nothing_but_the_time(tmp_path, monkeypatch):
+    """``encoder.look_ahead_chunks: N`` encodes N chunks per encoder call; every chunk still gets its own top-k against
+    the memory as it stood after the chunk before it and its own append (src/pipeline/vlm_extractor.py:44-74 order).
+    Stored rows, row numbers and reported neighbours (ids AND fp64 scores) must equal the N = 1 run exactly, with a
+    ragged last group, a ragged last chunk and a ring memory that wraps during the run."""
+    from vidmem import config as C, specs, synthetic as syn
+    from vidmem.extractor import FrameEmbeddingExtractor
+    monkeypatch.setitem(specs.SPECS, "vit_b16_2l", dict(specs.VIT_B16_224, layers=2))
+    monkeypatch.chdir(tmp_path)
+    frames = syn.frames_u8(5, 95, 96, 128)
+    clip = tmp_path / "clip.npz"
+    np.savez(clip, frames=frames, fps=np.float64(10.0))           # 9 chunks of 10 frames, 7 picked per chunk; 5 left over
+    runs = {}
+    enc = None
+    for n in (1, 4):
+        cfg = C.from_dict({
+            "video": {"chunk_size_seconds": 1.0, "frames_per_chunk": 7},
+            "encoder": {"arch": "vit_b16_2l", "dtype": "f16", "seed": 3, "top_k": 4, "look_ahead_chunks": n},
+            "memory": {"capacity": 48, "ring": True},
+        })
+        ex = FrameEmbeddingExtractor(cfg, encoder=enc)
+        enc = ex.encoder
+        out = json.load(open(asyncio.run(ex.process_video(str(clip), str(tmp_path / f"out{n}.json")))))
+        rid = out["metadata"]["run_id"]
+        res = [{**r, "processing_time": None,
+                "similar": [[(i.replace(rid, "RUN") if i else i, s) for i, s in fr] for fr in r["similar"]]}
+               for r in out["results"]]
+        runs[n] = (res, ex.memory.rows_tensor().clone(), len(ex.memory))
+    assert len(runs[1][0]) == 9 and runs[1][2] == 63
+    assert runs[1][0] == runs[4][0]
+    assert torch.equal(runs[1][1], runs[4][1]) and runs[1][2] == runs[4][2]
+    assert any(fr for r in runs[4][0] for fr in r["similar"])
+
+
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
 def test_hip_embedder_surface_against_the_encoder_oracle(dtype):
     from vidmem import specs, synthetic as syn

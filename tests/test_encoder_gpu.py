@@ -147,26 +147,61 @@ def test_projection_head_and_no_l2():
     assert rel(got.float().cpu().numpy(), want) < CONTRACT
 
 
-@pytest.mark.parametrize("name,dtype", [("vit_b16_224", "f16"), ("clip_l14_336", "bf16")])
+@pytest.mark.parametrize("name,dtype", [("vit_b16_224", "f16"), ("vit_b16_224_heavy", "f16"),
+                                        ("clip_l14_336", "bf16"), ("clip_l14_336_heavy", "bf16")])
 def test_full_models_match_golden(name, dtype, golden):
+    """Full-size models against the committed goldens: 8 ViT-B/16 frames and 4 CLIP-L/14-336 frames for each of two
+    weight sets - N(0, 0.02^2), and a heavy-tailed one (Student-t weights, six 6x LayerNorm outlier channels:
+    synthetic.encoder_weights tail="heavy").  Bars: the batch as a whole within the contract (fp16: 1e-3; bf16: 1.5 x
+    the operand-only floor, which no bf16-operand implementation can beat); every single frame within
+    max(contract, 1.5 x THAT frame's operand-only floor) - the floors are part of the golden file
+    (tests/golden/make_vit_golden.py), so the test evaluates nothing but the device output."""
     from vidmem import synthetic as syn
-    spec = V.SPECS[name]
+    spec = V.SPECS[name.replace("_heavy", "")]
     seed, std, n = golden[name + "/seed_std_n"]
-    w = syn.encoder_weights(spec, seed=int(seed), std=float(std))
-    px = syn.normal(1000 + int(seed), "pixels_" + name, (int(n), 3, spec["image"], spec["image"]))
+    tail = "heavy" if float(golden[name + "/tail"][0]) else "normal"
+    w = syn.encoder_weights(spec, seed=int(seed), std=float(std), tail=tail)
+    px = syn.normal(1000 + int(seed), "pixels_" + name.replace("_heavy", ""), (int(n), 3, spec["image"], spec["image"]))
     enc = _encoder(spec, w, dtype)
     got = enc.encode_patches(enc.patches_from_pixels(torch.from_numpy(px))).float().cpu().numpy()
+    assert np.isfinite(got).all()
+    floor = golden[name + "/floor_" + dtype]                     # [batch, frame 0, frame 1, ...]
     e_q, e_32 = rel(got, golden[name + "/" + dtype]), rel(got, golden[name + "/fp32"])
-    bar = CONTRACT if dtype == "f16" else floor_bar_full_clip()
-    print(f"{name} {dtype}: rel err vs quant-aware golden {e_q:.2e}, vs fp32 golden {e_32:.2e}, bar {bar:.2e}")
-    assert e_q < bar
-    assert e_32 < bar
-    # the same bar per frame and as an angle: for unit vectors 1 - cos = e^2 / 2 (directions compared in fp64; the
-    # 16-bit output's own norm is 1 only to an ulp)
+    bar = CONTRACT if dtype == "f16" else max(CONTRACT, FLOOR_SLACK * float(floor[0]))
     g64, f64 = got.astype(np.float64), golden[name + "/fp32"].astype(np.float64)
+    q64 = golden[name + "/" + dtype].astype(np.float64)
+    per32 = np.array([rel(g64[i], f64[i]) for i in range(g64.shape[0])])
+    perq = np.array([rel(g64[i], q64[i]) for i in range(g64.shape[0])])
+    frame_bar = np.maximum(CONTRACT, FLOOR_SLACK * floor[1:])
+    print(f"{name} {dtype}: batch rel err vs quant-aware golden {e_q:.2e}, vs fp32 golden {e_32:.2e}, bar {bar:.2e} "
+          f"(operand-only floor {floor[0]:.2e}); per frame vs fp32: worst {per32.max():.2e} (its floor "
+          f"{floor[1:][per32.argmax()]:.2e}, bar {frame_bar[per32.argmax()]:.2e}), vs quant-aware worst {perq.max():.2e}")
+    assert e_q < bar and e_32 < bar
+    assert (per32 < frame_bar).all(), (per32, frame_bar)
+    assert (perq < frame_bar).all(), (perq, frame_bar)
+    # the same per frame as an angle: for unit vectors 1 - cos = e^2 / 2 (directions compared in fp64; the 16-bit
+    # output's own norm is 1 only to an ulp)
     cos = (g64 * f64).sum(1) / (np.linalg.norm(g64, axis=1) * np.linalg.norm(f64, axis=1))
-    assert (1.0 - cos < 0.5 * bar * bar).all(), (1.0 - cos).max()
-    assert all(rel(g64[i], f64[i]) < bar for i in range(g64.shape[0]))
+    assert (1.0 - cos < 0.5 * frame_bar * frame_bar).all(), (1.0 - cos).max()
+
+
+def test_bf16_encoder_survives_activations_beyond_fp16_range():
+    """Residual-branch outputs (patch rows, attention projection, FC2) are stored as fp16 whatever the encoder's dtype
+    (csrc/vm_kernels.h EPI_DELTA16).  A bf16 model may have been chosen for its RANGE: an FC2 bias of 1e5 puts those
+    outputs past fp16's 65504.  The store must saturate instead of writing inf (which LayerNorm turns into NaN rows):
+    the embedding stays finite and - LayerNorm being scale-free, the huge bias common to every token - close to the
+    oracle's."""
+    from vidmem import synthetic as syn
+    spec = dict(arch="t", image=64, patch=16, hidden=256, layers=2, heads=4, mlp=512, act="quick_gelu", ln_eps=1e-5,
+                pre_ln=True, patch_bias=False, proj_dim=0, mean=(0.5,) * 3, std=(0.5,) * 3)
+    w = syn.encoder_weights(spec, seed=6, std=0.05)
+    w["l0.fc2_b"] = w["l0.fc2_b"].copy()
+    w["l0.fc2_b"][:8] = np.float32(1.0e5)
+    px = syn.normal(79, "px", (3, 3, 64, 64))
+    enc = _encoder(spec, w, "bf16")
+    got = enc.encode_patches(enc.patches_from_pixels(torch.from_numpy(px))).float().cpu().numpy()
+    assert np.isfinite(got).all()
+    assert np.allclose(np.linalg.norm(got, axis=1), 1.0, atol=8e-3)
 
 
 def test_batching_is_invisible(monkeypatch):

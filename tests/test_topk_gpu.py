@@ -461,3 +461,48 @@ def test_gemm_class_scan_tie_flood_marks_and_redoes():
     assert r[7].tolist() == sorted(flood.tolist())[:k]
     want_r, want_s = cref.cosine_topk(_bits(q[[7, 9, 100]]), _bits(m), k, dtype="f16")
     assert np.array_equal(r[[7, 9, 100]].cpu().numpy(), want_r) and np.array_equal(s[[7, 9, 100]].cpu().numpy(), want_s)
+
+
+def test_gemm_class_scan_full_size_properties_7040_queries_1m_rows():
+    """BASELINE configs[3] per-rank size (7,040 queries x 1,048,576 x 768 fp16 rows, top-10): size-independent
+    properties instead of an oracle pass - planted self-matches first with score 1, ordered distinct rows, returned
+    scores are the exact reference cosines of the returned rows, sharding invariance (top-k(whole) ==
+    merge(top-k(two row-interleaved halves)), global row ids), agreement with the exhaustive fp64 kernel on queries of
+    the first, a middle and the ragged last query tile."""
+    D, M, Q, k = 768, 1_048_576, 7040, 10
+    g = torch.Generator(device="cuda").manual_seed(2026)
+    from vidmem.memory import EmbeddingMemory, topk_merge
+    mem = EmbeddingMemory(M, D, "f16")
+    halves = [EmbeddingMemory(M // 2, D, "f16") for _ in range(2)]
+    for lo in range(0, M, 262_144):
+        x = torch.randn((262_144, D), generator=g, device="cuda", dtype=torch.float32)
+        x = (x / x.norm(dim=1, keepdim=True)).to(torch.float16)
+        mem.append(x)
+        for part in range(2):
+            halves[part].append(x[part::2])
+    q = torch.randn((Q, D), generator=g, device="cuda", dtype=torch.float32).to(torch.float16)
+    planted = {0: 3, 255: 4_095, 256: 4_096, 1000: 32_767, 3333: 262_144, 6911: 1_048_575, 7039: 777_777}
+    rows_t = mem.rows_tensor()
+    for qi, row in planted.items():
+        q[qi] = rows_t[row]
+    mem.reset_uncertified()
+    s, r = mem.topk(q, k)
+    assert mem.uncertified_count == 0
+    s_np, r_np = s.cpu().numpy(), r.cpu().numpy()
+    for qi, row in planted.items():
+        assert r_np[qi, 0] == row and abs(s_np[qi, 0] - 1.0) < 1e-12, (qi, row, r_np[qi, 0])
+    assert (np.diff(s_np, axis=1) <= 0).all() and (r_np >= 0).all() and (r_np < M).all()
+    assert (np.sort(r_np, axis=1)[:, 1:] != np.sort(r_np, axis=1)[:, :-1]).all()
+    for qi in (5, 4000, 7038):
+        ex = mem.cosine_exact(q[qi:qi + 1], rows_t[r[qi]]).cpu().numpy()
+        assert np.array_equal(ex[0], s_np[qi])
+    parts = [h.topk(q, k, row_stride=2, row_offset=p) for p, h in enumerate(halves)]
+    ms, mr = topk_merge(mem.ctx, torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
+    assert np.array_equal(mr.cpu().numpy(), r_np) and np.array_equal(ms.cpu().numpy(), s_np)
+    pick = torch.tensor([1, 3500, 6912, 7039], device="cuda")
+    s2, r2 = mem.topk(q[pick], k, exact=True)
+    assert np.array_equal(r2.cpu().numpy(), r_np[pick.cpu().numpy()])
+    assert np.array_equal(s2.cpu().numpy(), s_np[pick.cpu().numpy()])
+    for h in halves:
+        h.close()
+    mem.close()
