@@ -22,6 +22,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("VIDGRAPH_LOG_LEVEL", "WARNING")   # the drop-in classes log to stdout like the reference's; this
+                                                          # program's stdout carries exactly one JSON line
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -191,6 +193,13 @@ def pmc_traffic(kernel: str, shape: str):
     return None, {"file": None, "kernel": kernel, "run_shape": shape, "note": "no committed PMC summary holds this kernel"}
 
 
+def note(msg: str) -> None:
+    """Progress line on stderr (rank 0's stdout carries exactly one JSON line)."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        sys.stderr.write(f"[bench {time.strftime('%H:%M:%S')}] {msg}\n")
+        sys.stderr.flush()
+
+
 def free_port() -> int:
     import socket
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
@@ -287,6 +296,7 @@ def main():
         memory.append(emb)
         return scores, rows
 
+    note(f"main leg: {F} frames per step, {R}-row shard, world {world}")
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
@@ -409,6 +419,7 @@ def main():
 
     # ---- kNN half of the metric: Q=16 queries/launch over a 1M x 768 index (single GPU part of every rank 0) ----
     if rank == 0 and world == 1 and not args.no_knn:
+        note("knn leg")
         del frame_pool
         Mk = args.knn_rows
         big = EmbeddingMemory(Mk, D, "f16", device=local_rank)
@@ -459,6 +470,7 @@ def main():
     # -> 8-part merge of its own 880).  Here the other ranks' queries are embeddings of other synthetic frames, the
     # other ranks' candidate lists are this shard's lists of their queries; nothing crosses a link.
     if rank == 0 and world == 1 and not args.no_c4:
+        note("c4 rank-share leg")
         W4 = args.c4_world
         R4 = 1_048_576
         shard = EmbeddingMemory(R4, D, "f16", ring=True, device=local_rank)
@@ -527,6 +539,7 @@ def main():
     # chunks per encoder call from frames resident in HBM; this leg drives the drop-in class from a file on the host:
     # frame reads, pinned staging, H2D, per-chunk top-k + append, JSON and metrics files included.
     if rank == 0 and world == 1 and not args.no_extractor:
+        note("extractor (plugin path) leg")
         import asyncio
         import tempfile
         from vidmem import config as vcfg
@@ -568,6 +581,7 @@ def main():
 
     # ---- streaming leg (BASELINE configs[4]): 16 x 1080p frames per chunk, rolling 2M-row memory, one hipGraph ------
     if rank == 0 and world == 1 and not args.no_streaming:
+        note("streaming leg")
         from vidmem.streaming import StreamingSession
         Ms = args.stream_rows
         ring = EmbeddingMemory(Ms, D, "f16", ring=True, device=local_rank)
@@ -597,10 +611,11 @@ def main():
         # available, host clock, H2D included; the only waits are on the replay's own event (no device-wide sync).
         # Default period = one 30 fps FRAME time per 16-frame chunk, i.e. the feed runs 16x faster than real time
         # (2,000 chunks at the real 533 ms chunk period would take 18 minutes); --stream-period-ms 533.3 is real time.
+        note(f"streaming feed: {args.stream_replays} chunks, one every {args.stream_period_ms:.1f} ms")
         import queue
         import threading
         n_feed, period = args.stream_replays, args.stream_period_ms * 1e-3
-        pool_n = 6
+        pool_n = 8          # x 256 per-push constants = 2,048 distinct chunks before one repeats (a repeat plants exact ties)
         pool = np.random.default_rng(5).integers(0, 256, size=(pool_n, 16, 1080, 1920, 3), dtype=np.uint8)
         stager = sess.stager
         ready: "queue.Queue" = queue.Queue()
@@ -609,24 +624,26 @@ def main():
         slot_free = threading.Semaphore(1)
 
         def producer():
-            t_next = time.perf_counter()
-            for i in range(n_feed):
-                slot_free.acquire()
-                view = stager.next_slot()
-                # a new, distinct chunk per push without a 100 MB RNG call: pool chunk + a per-push constant (mod 256)
-                np.add(pool[i % pool_n], np.uint8((i // pool_n) * 37 + 1), out=view)
-                t_next += period
-                delay = t_next - time.perf_counter()
-                if delay > 0:
-                    time.sleep(delay)
-                ready.put(time.perf_counter())
-            ready.put(None)
+            try:
+                t_next = time.perf_counter()
+                for i in range(n_feed):
+                    slot_free.acquire()
+                    view = stager.next_slot()
+                    # a new, distinct chunk per push without a 100 MB RNG call: pool chunk + a per-push constant (mod 256)
+                    np.add(pool[i % pool_n], np.uint8(((i // pool_n) * 37 + 1) % 256), out=view)
+                    t_next += period
+                    delay = t_next - time.perf_counter()
+                    if delay > 0:
+                        time.sleep(delay)
+                    ready.put(time.perf_counter())
+            finally:
+                ready.put(None)      # also on an exception: the consumer must never wait for a dead producer
 
         th = threading.Thread(target=producer, daemon=True)
         th.start()
         lat_f = []
         while True:
-            t_arr = ready.get()
+            t_arr = ready.get(timeout=120.0)
             if t_arr is None:
                 break
             ticket = stager.commit(16)
@@ -664,6 +681,7 @@ def main():
 
     # ---- BASELINE configs[2] leg: CLIP-ViT-L/14-336 bf16 encoder + top-20 over a 1M x 1024 bf16 index --------------
     if rank == 0 and world == 1 and not args.no_c3:
+        note("c3 leg (CLIP-L/14-336 bf16)")
         del enc
         torch.cuda.empty_cache()
         spec3 = specs.CLIP_L14_336
@@ -726,6 +744,7 @@ def main():
         del enc3, fr3
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        note("cpu baseline")
         out["cpu_baseline"] = cpu_baseline(spec, weights, mem_rows[:R].cpu().numpy(), k)
 
     if rank == 0:

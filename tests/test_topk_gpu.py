@@ -506,3 +506,25 @@ def test_gemm_class_scan_full_size_properties_7040_queries_1m_rows():
     for h in halves:
         h.close()
     mem.close()
+
+
+@pytest.mark.parametrize("k", [32, 58])
+def test_large_k_on_a_large_memory_stays_on_the_fast_path(k):
+    """k >= 27 keeps 64 candidates per query (KL = 64).  The previous sample-based cut expected ~4 k candidates per
+    query in its last pass on memories of a million rows - the capacity of a candidate buffer - so a third of the
+    queries overflowed into the exhaustive redo.  The incremental cascade emits ~7 KL per pass whatever the size:
+    nothing may be redone here, and the answers equal the exhaustive kernel's."""
+    D, M, Q = 256, 1_000_000, 64
+    g = torch.Generator(device="cuda").manual_seed(58)
+    from vidmem.memory import EmbeddingMemory
+    mem = EmbeddingMemory(M, D, "f16")
+    for lo in range(0, M, 250_000):
+        x = torch.randn((250_000, D), generator=g, device="cuda", dtype=torch.float32)
+        mem.append((x / x.norm(dim=1, keepdim=True)).to(torch.float16))
+    q = torch.randn((Q, D), generator=g, device="cuda", dtype=torch.float32).to(torch.float16)
+    mem.reset_uncertified()
+    s, r = mem.topk(q, k)
+    assert mem.uncertified_count == 0
+    s2, r2 = mem.topk(q[:6], k, exact=True)
+    assert np.array_equal(r2.cpu().numpy(), r[:6].cpu().numpy()) and np.array_equal(s2.cpu().numpy(), s[:6].cpu().numpy())
+    mem.close()
