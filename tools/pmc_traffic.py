@@ -2,7 +2,9 @@
 """Fold two rocprofv3 --pmc runs of bench.py (FETCH_SIZE and WRITE_SIZE, separate passes as
 MI355X_MICROARCH.md prescribes: both do not fit one pass) into profiles/<name>.json: per-kernel average HBM/fabric
 bytes per launch.  gfx950 correction: FETCH_SIZE tallies 64 B per 128-B read request -> doubled; WRITE_SIZE is exact.
-usage: pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json>"""
+usage: pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> [leg=shape ...]
+  leg=shape: the launch shapes the profiled bench run used, e.g. main=F880,mb441,R100000,k10 c3=F2128,mb112 - bench.py
+  only quotes a kernel's traffic when its own run has the same shape (bench.py pmc_traffic)."""
 import collections, csv, json, sys
 
 def per_kernel(path, counter):
@@ -27,7 +29,7 @@ def short(name):
 fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
 write = per_kernel(sys.argv[2], "WRITE_SIZE")
 out = {"unit": "bytes per launch (average)", "correction": "read = 2 * FETCH_SIZE * 1024 (gfx950), write = WRITE_SIZE * 1024",
-       "kernels": {}}
+       "shapes": dict(a.split("=", 1) for a in sys.argv[4:]), "kernels": {}}
 for k in sorted(fetch):
     f, n = fetch[k]
     w = write.get(k, (0.0, 0))[0]
