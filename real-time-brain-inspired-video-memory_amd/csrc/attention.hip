@@ -22,6 +22,16 @@ typedef short s4v __attribute__((__vector_size__(4 * sizeof(short))));
 typedef __attribute__((address_space(3))) s4v *lds_s4v_ptr;
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *gbl_ptr_t;
+typedef const __attribute__((address_space(3))) char *lds_cptr;   // 32-bit LDS byte address that stays one through asm
+
+// "Does any of the eight scores of a 32-key step exceed the row's reference?" as eight compares OR-ed on the scalar
+// side.  Written as fmaxf() chains the compiler first canonicalises every MFMA output (v_max_f32 x, x: eleven vector
+// instructions for one value); inline-asm v_max3_f32 on MFMA results is not an option - the hazard recogniser does not
+// see an asm statement's reads, and the wait states between a matrix write and a vector read are software's job.
+__device__ __forceinline__ bool any_above(const f32x4 a, const f32x4 b, float ref) {
+    return (a[0] > ref) | (a[1] > ref) | (a[2] > ref) | (a[3] > ref) | (b[0] > ref) | (b[1] > ref) | (b[2] > ref) |
+           (b[3] > ref);
+}
 
 // One 16-query tile against all keys of the (frame, head) staged in LDS: scores, softmax, P.V, context store.
 template <int DT, int NT, bool EXACT>
@@ -194,21 +204,35 @@ __device__ __forceinline__ void attend_tile_pass2(const char *kl, const char *vl
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // running LDS pointers, advanced by one 32-key step (4 KiB) per trip: every read of a step is base + a small
+    // immediate (the V image sits 74 KiB behind K: as `index * stride + image offset` each of the eight V reads cost
+    // two address instructions per step)
+    lds_cptr kp0 = (lds_cptr)p0, kp1 = (lds_cptr)p1;
+    lds_cptr vp[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) vp[dt] = (lds_cptr)(vrow + voff[dt]);
     auto step = [&](int ks, bool masked0, bool has1, bool masked1) {
         // every LDS read of the step is issued up front - the K fragments of both key tiles and the eight transposed V
         // fragments (they do not depend on P) - so one LDS latency is exposed per 32 keys instead of six
-        const char *row_lo = vrow + ks * 32 * 128;
         const int hi_off = has1 ? 16 * 128 : 0;  // odd NT: the last half step re-reads valid rows against P = 0
-        const vec8 ka0 = *reinterpret_cast<const vec8 *>(p0 + (2 * ks) * 2048);
-        const vec8 ka1 = *reinterpret_cast<const vec8 *>(p1 + (2 * ks) * 2048);
-        const vec8 kb0 = *reinterpret_cast<const vec8 *>(p0 + (2 * ks + (has1 ? 1 : 0)) * 2048);
-        const vec8 kb1 = *reinterpret_cast<const vec8 *>(p1 + (2 * ks + (has1 ? 1 : 0)) * 2048);
+        typedef const __attribute__((address_space(3))) vec8 *lds_vec8_ptr;
+        const vec8 ka0 = *(lds_vec8_ptr)(kp0);
+        const vec8 ka1 = *(lds_vec8_ptr)(kp1);
+        const vec8 kb0 = *(lds_vec8_ptr)(kp0 + (has1 ? 2048 : 0));
+        const vec8 kb1 = *(lds_vec8_ptr)(kp1 + (has1 ? 2048 : 0));
         s4v vlo[4], vhi[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-            vlo[dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr)(row_lo + voff[dt]));
-            vhi[dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr)(row_lo + hi_off + voff[dt]));
+            vlo[dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr)(vp[dt]));
+            vhi[dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr)(vp[dt] + hi_off));
         }
+        kp0 += 4096;
+        kp1 += 4096;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) vp[dt] += 4096;
+        // keep them as six loop-carried registers (the compiler otherwise re-derives every address from one induction
+        // variable plus the image offset, which does not fit a ds_read immediate: 14 adds per step instead of 6)
+        asm volatile("" : "+v"(kp0), "+v"(kp1), "+v"(vp[0]), "+v"(vp[1]), "+v"(vp[2]), "+v"(vp[3]));
         f32x4 a[2];
         a[0] = E::mfma16(ka0, qa, f32x4{0.f, 0.f, 0.f, 0.f});
         a[0] = E::mfma16(ka1, qb, a[0]);
@@ -233,9 +257,9 @@ __device__ __forceinline__ void attend_tile_pass2(const char *kl, const char *vl
             // later ones where the row maximum grows by more than the slack - are the two shuffles, the rescale of
             // the sums and the new reference paid.  (With the reference tied to the exact running maximum every step
             // carried a dependent chain max -> shuffle -> max -> shuffle -> ballot of ~300 cycles.)
-            const float lm_own = fmaxf(fmaxf(fmaxf(a[0][0], a[0][1]), fmaxf(a[0][2], a[0][3])),
-                                       fmaxf(fmaxf(a[1][0], a[1][1]), fmaxf(a[1][2], a[1][3])));
-            if (__ballot(lm_own > run_hi) != 0ull) {  // wave-uniform
+            if (__ballot(any_above(a[0], a[1], run_hi)) != 0ull) {  // wave-uniform
+                const float lm_own = fmaxf(fmaxf(fmaxf(a[0][0], a[0][1]), fmaxf(a[0][2], a[0][3])),
+                                           fmaxf(fmaxf(a[1][0], a[1][1]), fmaxf(a[1][2], a[1][3])));
                 float lm = fmaxf(lm_own, __shfl_xor(lm_own, 16, 64));
                 lm = fmaxf(lm, __shfl_xor(lm, 32, 64));
                 const float m_new = fmaxf(run_m, lm);  // rows whose scores stayed below keep their reference (f = 1)
@@ -256,8 +280,7 @@ __device__ __forceinline__ void attend_tile_pass2(const char *kl, const char *vl
             f32x2 p23 = __builtin_elementwise_fma(f32x2{a[u][2], a[u][3]}, c2, n2);
             p01 = f32x2{__builtin_amdgcn_exp2f(p01.x), __builtin_amdgcn_exp2f(p01.y)};
             p23 = f32x2{__builtin_amdgcn_exp2f(p23.x), __builtin_amdgcn_exp2f(p23.y)};
-            sum2 += p01;
-            sum2 += p23;
+            sum2 += p01 + p23;
             pe[4 * u + 0] = E::from_float(p01.x);
             pe[4 * u + 1] = E::from_float(p01.y);
             pe[4 * u + 2] = E::from_float(p23.x);
@@ -293,6 +316,228 @@ __device__ __forceinline__ void attend_tile_pass2(const char *kl, const char *vl
             __builtin_memcpy(&pk, oe, 8);
             *reinterpret_cast<uint2 *>(dst + dt * 16) = pk;
         }
+    }
+}
+
+// TWO query tiles per wave and walk (32 queries): the K and V fragments of a 32-key step are read from LDS once and feed
+// both tiles' MFMAs, and the two tiles' softmax chains (MFMA -> max test -> exp2 -> pack -> MFMA) are independent
+// instruction streams inside one wave, so one chain's latencies are covered by the other's work.  Same lazily raised
+// reference per tile as the one-tile walk.  Measured (CLIP-L/14-336 bf16, 448 frames, ms of attention): one tile per
+// walk, 16 waves 26.0; pairs, 8 / 10 / 12 waves 27.4 (before the address trimming) / 28.3 / 24.9 - a 4 % gain, i.e.
+// the walk is not latency-bound; what it IS bound by has not been found (matrix pipe 24 % busy, LDS ~27 %, the
+// vector port ~65 % by instruction count; the K/V fill of a workgroup is 17 % of its life and overlaps nothing).
+template <int DT, int NT, bool EXACT>
+__device__ __forceinline__ void attend_pair_online(const char *kl, const char *vl,
+                                                   const typename vm_elem<DT>::vec8 (&qa)[2],
+                                                   const typename vm_elem<DT>::vec8 (&qb)[2], int T, int lane,
+                                                   const bool (&qvalid)[2], uint16_t *const (&dst_row)[2]) {
+    using E = vm_elem<DT>;
+    using vec8 = typename E::vec8;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef short s8v __attribute__((__vector_size__(8 * sizeof(short))));
+    constexpr int NS = (NT + 1) / 2;
+    constexpr float ONLINE_SLACK = 6.0f;
+    const int r16 = lane & 15, h = lane >> 4;
+    const int tq = r16 >> 2, tp = r16 & 3;
+    const float scale_log2e = 0.125f * 1.44269504088896340736f;
+    const f32x2 c2 = {scale_log2e, scale_log2e};
+    const char *p0 = kl + r16 * 128 + ((h ^ (r16 & 7)) << 4);
+    const char *p1 = kl + r16 * 128 + (((h + 4) ^ (r16 & 7)) << 4);
+    const int vsw = (4 * h + tq) & 7;
+    const char *vrow = vl + (4 * h + tq) * 128 + (tp & 1) * 8;
+    int voff[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) voff[dt] = ((2 * dt + (tp >> 1)) ^ vsw) << 4;
+    float run_m[2] = {-1e30f, -1e30f}, run_hi[2] = {-1e30f, -1e30f};
+    f32x2 n2[2] = {{1e30f * scale_log2e, 1e30f * scale_log2e}, {1e30f * scale_log2e, 1e30f * scale_log2e}};
+    f32x2 sum2[2] = {{0.f, 0.f}, {0.f, 0.f}};
+    f32x4 o[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    lds_cptr kp0 = (lds_cptr)p0, kp1 = (lds_cptr)p1;   // running LDS pointers: one 32-key step = 4 KiB
+    lds_cptr vp[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) vp[dt] = (lds_cptr)(vrow + voff[dt]);
+    auto step = [&](int ks, bool masked0, bool has1, bool masked1) {
+        const int hi_off = has1 ? 16 * 128 : 0;
+        typedef const __attribute__((address_space(3))) vec8 *lds_vec8_ptr;
+        const vec8 ka0 = *(lds_vec8_ptr)(kp0);
+        const vec8 ka1 = *(lds_vec8_ptr)(kp1);
+        const vec8 kb0 = *(lds_vec8_ptr)(kp0 + (has1 ? 2048 : 0));
+        const vec8 kb1 = *(lds_vec8_ptr)(kp1 + (has1 ? 2048 : 0));
+        s4v vlo[4], vhi[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            vlo[dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr)(vp[dt]));
+            vhi[dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr)(vp[dt] + hi_off));
+        }
+        kp0 += 4096;
+        kp1 += 4096;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) vp[dt] += 4096;
+        // keep them as six loop-carried registers (the compiler otherwise re-derives every address from one induction
+        // variable plus the image offset, which does not fit a ds_read immediate: 14 adds per step instead of 6)
+        asm volatile("" : "+v"(kp0), "+v"(kp1), "+v"(vp[0]), "+v"(vp[1]), "+v"(vp[2]), "+v"(vp[3]));
+        f32x4 a[2][2];
+        bool out_of_slack = false;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            a[t][0] = E::mfma16(ka0, qa[t], f32x4{0.f, 0.f, 0.f, 0.f});
+            a[t][0] = E::mfma16(ka1, qb[t], a[t][0]);
+            a[t][1] = E::mfma16(kb0, qa[t], f32x4{0.f, 0.f, 0.f, 0.f});
+            a[t][1] = E::mfma16(kb1, qb[t], a[t][1]);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (masked0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[t][0][j] = ((2 * ks) * 16 + 4 * h + j < T) ? a[t][0][j] : -INFINITY;
+            }
+            if (!has1) {
+                a[t][1] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            } else if (masked1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[t][1][j] = ((2 * ks + 1) * 16 + 4 * h + j < T) ? a[t][1][j] : -INFINITY;
+            }
+            out_of_slack |= any_above(a[t][0], a[t][1], run_hi[t]);
+        }
+        if (__ballot(out_of_slack) != 0ull) {  // wave-uniform, rare after the first step
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float lm_own = fmaxf(fmaxf(fmaxf(a[t][0][0], a[t][0][1]), fmaxf(a[t][0][2], a[t][0][3])),
+                                           fmaxf(fmaxf(a[t][1][0], a[t][1][1]), fmaxf(a[t][1][2], a[t][1][3])));
+                float lm = fmaxf(lm_own, __shfl_xor(lm_own, 16, 64));
+                lm = fmaxf(lm, __shfl_xor(lm, 32, 64));
+                // a row whose scores stayed within its slack keeps its reference: f = 1 exactly
+                const float m_new = lm > run_hi[t] ? lm : run_m[t];
+                const float f = __builtin_amdgcn_exp2f((run_m[t] - m_new) * scale_log2e);
+                sum2[t] *= f32x2{f, f};
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) o[t][dt] *= f32x4{f, f, f, f};
+                run_m[t] = m_new;
+                run_hi[t] = m_new + ONLINE_SLACK / scale_log2e;
+                const float neg = -m_new * scale_log2e;
+                n2[t] = f32x2{neg, neg};
+            }
+        }
+        vec8 pf[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            uint16_t pe[8];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                f32x2 p01 = __builtin_elementwise_fma(f32x2{a[t][u][0], a[t][u][1]}, c2, n2[t]);
+                f32x2 p23 = __builtin_elementwise_fma(f32x2{a[t][u][2], a[t][u][3]}, c2, n2[t]);
+                p01 = f32x2{__builtin_amdgcn_exp2f(p01.x), __builtin_amdgcn_exp2f(p01.y)};
+                p23 = f32x2{__builtin_amdgcn_exp2f(p23.x), __builtin_amdgcn_exp2f(p23.y)};
+                sum2[t] += p01 + p23;
+                pe[4 * u + 0] = E::from_float(p01.x);
+                pe[4 * u + 1] = E::from_float(p01.y);
+                pe[4 * u + 2] = E::from_float(p23.x);
+                pe[4 * u + 3] = E::from_float(p23.y);
+            }
+            __builtin_memcpy(&pf[t], pe, 16);
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const s8v av = __builtin_shufflevector(vlo[dt], vhi[dt], 0, 1, 2, 3, 4, 5, 6, 7);
+            o[0][dt] = E::mfma16(__builtin_bit_cast(vec8, av), pf[0], o[0][dt]);
+            o[1][dt] = E::mfma16(__builtin_bit_cast(vec8, av), pf[1], o[1][dt]);
+        }
+    };
+    constexpr int FULL_STEPS = EXACT ? (NT - 1) / 2 : 0;
+    int ks = 0;
+#pragma unroll 1
+    for (; ks < FULL_STEPS; ++ks) step(ks, false, true, false);
+#pragma unroll 1
+    for (; ks < NS; ++ks) step(ks, true, 2 * ks + 1 < NT, true);
+
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        float sum = sum2[t].x + sum2[t].y;
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+        if (qvalid[t]) {
+            uint16_t *dst = dst_row[t] + 4 * h;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                uint16_t oe[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) oe[j] = E::from_float(o[t][dt][j] * inv);
+                uint2 pk;
+                __builtin_memcpy(&pk, oe, 8);
+                *reinterpret_cast<uint2 *>(dst + dt * 16) = pk;
+            }
+        }
+    }
+}
+
+// One workgroup of NW waves per (frame, head), every wave walks PAIRS of query tiles (attend_pair_online): pairs wave,
+// wave + NW, ...  With 37 tiles = 19 pairs and 12 waves seven waves take two pairs and five take one (16 waves with
+// one tile per walk: five waves take three tiles while eleven take two).
+template <int DT, int NT, bool EXACT, int NW>
+__global__ void __launch_bounds__(NW * 64, 1)
+    attention_pair_kernel(const uint16_t *__restrict__ qkv, uint16_t *__restrict__ ctx_out, int T, int heads,
+                          int qt_lim) {
+    using E = vm_elem<DT>;
+    using vec8 = typename E::vec8;
+    constexpr int ROWS = NT * 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *kl = smem, *vl = smem + (size_t)ROWS * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, h = lane >> 4;
+    const int b = blockIdx.x / heads, head = blockIdx.x - b * heads;
+    const int H = heads * 64;
+    const size_t M = (size_t)(gridDim.x / heads) * T;
+    auto block = [&](int part) { return qkv + ((size_t)(part * heads + head) * M + (size_t)b * T) * 64; };
+    auto load_q = [&](int qt, vec8 &q0, vec8 &q1) {
+        int qtok = qt * 16 + r16;
+        if (qtok > T - 1) qtok = T - 1;
+        const uint16_t *qp = block(0) + (size_t)qtok * 64;
+        q0 = __builtin_bit_cast(vec8, *reinterpret_cast<const uint4 *>(qp + 8 * h));
+        q1 = __builtin_bit_cast(vec8, *reinterpret_cast<const uint4 *>(qp + 32 + 8 * h));
+    };
+    const int srow = lane >> 3, scp = lane & 7;
+    auto stage = [&](int part, char *dst) {  // rows past T re-read row T-1 (masked / P = 0 later)
+        const char *src = reinterpret_cast<const char *>(block(part));
+#pragma unroll 4
+        for (int grp = wave; grp < ROWS / 8; grp += NW) {
+            int key = grp * 8 + srow;
+            key = key > T - 1 ? T - 1 : key;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + (size_t)key * 128 + ((scp ^ srow) << 4)),
+                                             (lds_ptr_t)(dst + grp * 1024), 16, 0, 2);  // nt: read once
+        }
+    };
+    const int npairs = (qt_lim + 1) / 2;
+    vec8 qa[2], qb[2];
+    if (wave < npairs) {
+        load_q(2 * wave, qa[0], qb[0]);
+        load_q(2 * wave + 1, qa[1], qb[1]);
+    }
+    stage(1, kl);
+    stage(2, vl);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int pr = wave; pr < npairs; pr += NW) {
+        bool qvalid[2];
+        uint16_t *dst[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int qt = 2 * pr + t;
+            const int qtok = qt * 16 + r16;
+            qvalid[t] = qt < qt_lim && qtok < T;
+            dst[t] = ctx_out + ((size_t)b * T + (qvalid[t] ? qtok : 0)) * H + head * 64;
+        }
+        const vec8 ca[2] = {qa[0], qa[1]}, cb[2] = {qb[0], qb[1]};
+        if (pr + NW < npairs) {
+            load_q(2 * (pr + NW), qa[0], qb[0]);
+            load_q(2 * (pr + NW) + 1, qa[1], qb[1]);
+        }
+        attend_pair_online<DT, NT, EXACT>(kl, vl, ca, cb, T, lane, qvalid, dst);
     }
 }
 
@@ -363,8 +608,29 @@ int launch_long(vm_ctx *ctx, const uint16_t *qkv, uint16_t *out, int B, int T, i
         const char *e = getenv("VIDMEM_ATTN_ONLINE");
         online_env = e ? atoi(e) : 1;
     }
+    static int pair_env = -1;
+    if (pair_env < 0) {
+        const char *e = getenv("VIDMEM_ATTN_PAIR");   // waves of the two-tiles-per-walk kernel; 0 = one tile per walk
+        pair_env = e ? atoi(e) : 12;
+    }
     vm_prof_scope prof(ctx, VM_PROF_ATTENTION, st);
-    if (online_env) {
+    if (online_env && pair_env > 0) {
+        const int ql = qt_lim < NT ? qt_lim : NT;
+#define VM_PAIR_GO(NWV)                                                                                              \
+    {                                                                                                                \
+        auto kern = attention_pair_kernel<DT, NT, EXACT, NWV>;                                                       \
+        static bool attr_set = false;                                                                                \
+        if (!attr_set) {                                                                                             \
+            VM_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            attr_set = true;                                                                                         \
+        }                                                                                                            \
+        kern<<<B * heads, NWV * 64, lds, st>>>(qkv, out, T, heads, ql);                                              \
+    }
+        if (pair_env == 8) VM_PAIR_GO(8)
+        else if (pair_env == 10) VM_PAIR_GO(10)
+        else VM_PAIR_GO(12)
+#undef VM_PAIR_GO
+    } else if (online_env) {
         auto kern = attention_long_kernel<DT, NT, EXACT, 16, true>;
         static bool attr_set = false;
         if (!attr_set) {
