@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--no-extractor", action="store_true", help="skip the plugin-path leg (process_video on a host clip)")
     ap.add_argument("--extractor-frames", type=int, default=4096)
     ap.add_argument("--look-ahead-chunks", type=int, default=55, help="chunks per encoder call in the plugin-path leg")
+    ap.add_argument("--no-two-stream", action="store_true", help="skip the two-stream encoder A/B beside the main leg")
     ap.add_argument("--no-c4", action="store_true", help="skip the one-GPU rank-share leg of BASELINE configs[3]")
     ap.add_argument("--c4-world", type=int, default=8, help="ranks of the job whose per-rank step the c4 leg runs")
     ap.add_argument("--topk", type=int, default=10)
@@ -334,6 +335,38 @@ def main():
     ctx.profile_mask(None)
     uncert = retriever.uncertified_total()   # queries the fp32 scan could not certify; redone exhaustively in-step
 
+    # ---- A/B beside the headline: the same steps through an encoder created in its two-stream mode -----------------
+    two_stream = None
+    if rank == 0 and world == 1 and not args.no_two_stream and F > mb_frames:
+        os.environ["VIDMEM_ENC_DUAL"] = "1"
+        enc2 = FrameEncoder(spec, weights, dtype="f16", device=local_rank)
+        del os.environ["VIDMEM_ENC_DUAL"]
+        main_enc = enc
+
+        def step2(i):
+            emb = enc2.embed_frames(frame_pool[i % pool_steps])
+            scores, rows = retriever.search(emb, k)
+            memory.append(emb)
+            return emb
+        same = torch.equal(step2(0), main_enc.embed_frames(frame_pool[0]))
+        for i in range(2):
+            step2(i)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        n2 = max(4, args.steps // 2)
+        for i in range(n2):
+            step2(3 + i)
+        torch.cuda.synchronize()
+        dt2 = (time.perf_counter() - t2) / n2
+        two_stream = {
+            "what": "the same step with the encoder created under VIDMEM_ENC_DUAL=1: micro-batch passes alternate between "
+                    "two internal streams, LayerNorm in its low-register build runs beside the other pass's GEMMs "
+                    "(csrc/encoder.hip vm_encode); off by default because per-kernel event / rocprofv3 durations then "
+                    "include cross-stream waiting",
+            "frames_per_s": F / dt2, "ms_per_step": dt2 * 1e3, "embeddings_bit_identical": bool(same),
+        }
+        del enc2
+
     t = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -358,6 +391,8 @@ def main():
                                    + " of queries and candidates") if world > 1 else "single GPU"},
         "queries_per_s": value, "uncertified_queries_redone": uncert,
     }
+    if two_stream is not None:
+        out["two_stream_encoder"] = two_stream
 
     if rank == 0:
         # ---- roofline of the dominant kernel (by total time inside the timed region) ------------------------

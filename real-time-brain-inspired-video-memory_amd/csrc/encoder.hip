@@ -169,6 +169,81 @@ __global__ void __launch_bounds__(256) resid_layernorm_kernel(float *__restrict_
     }
 }
 
+// The same pass for co-residency with the persistent GEMM (vm_encode's two-stream mode): that kernel holds two waves of
+// 224 VGPRs on every SIMD and all but 4 KiB of the LDS, so only a kernel of <= 64 VGPRs and no LDS is admitted beside
+// it.  One row per wave, the 16-bit branch outputs kept packed until they are added, gamma / beta fetched (from L2)
+// only after the statistics: same values, same additions in the same order, bit for bit.
+template <int DT, int VPL, bool NT>
+__global__ void __launch_bounds__(256, 8) resid_layernorm_lowreg_kernel(float *__restrict__ x32,
+                                                                        const uint16_t *__restrict__ delta16,
+                                                                        const uint16_t *__restrict__ deltaB16,
+                                                                        int write_x, const float *__restrict__ gamma,
+                                                                        const float *__restrict__ beta, float eps,
+                                                                        uint16_t *__restrict__ out16, int rows, int H,
+                                                                        int rstride) {
+    using E = vm_elem<DT>;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const size_t base = (size_t)row * rstride * H;
+    float4 v[VPL];
+    const float4 *xr = reinterpret_cast<const float4 *>(x32 + base);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) v[i] = ld_f4<NT>(xr + lane + 64 * i);
+    if (delta16) {
+        float4 d[VPL];
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) d[i] = load4_16<VM_F16, NT>(delta16 + base + 4 * (lane + 64 * i));
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            v[i].x += d[i].x;
+            v[i].y += d[i].y;
+            v[i].z += d[i].z;
+            v[i].w += d[i].w;
+        }
+    }
+    if (deltaB16) {
+        float4 d[VPL];
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) d[i] = load4_16<VM_F16, NT>(deltaB16 + base + 4 * (lane + 64 * i));
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            v[i].x += d[i].x;
+            v[i].y += d[i].y;
+            v[i].z += d[i].z;
+            v[i].w += d[i].w;
+        }
+    }
+    if (write_x > 1 ? row % write_x == 0 : write_x) {
+        float4 *xw = reinterpret_cast<float4 *>(x32 + base);
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) st_f4<NT>(xw + lane + 64 * i, v[i]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    const float mean = wave_sum(sum) / (float)H;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, e = v[i].w - mean;
+        sq += (a * a + b * b) + (c * c + e * e);
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)H + eps);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const float4 g4 = reinterpret_cast<const float4 *>(gamma)[lane + 64 * i];
+        const float4 b4 = reinterpret_cast<const float4 *>(beta)[lane + 64 * i];
+        uint16_t o[4] = {E::from_float((v[i].x - mean) * rstd * g4.x + b4.x),
+                         E::from_float((v[i].y - mean) * rstd * g4.y + b4.y),
+                         E::from_float((v[i].z - mean) * rstd * g4.z + b4.z),
+                         E::from_float((v[i].w - mean) * rstd * g4.w + b4.w)};
+        uint2 pk;
+        __builtin_memcpy(&pk, o, 8);
+        st_u2<NT>(reinterpret_cast<uint2 *>(out16 + base) + lane + 64 * i, pk);
+    }
+}
+
 // Embedding assembly, one wave per token row: x32[frame*T + tok] = (tok ? patch16[frame*P + tok - 1] : cls) + pos[tok],
 // followed by the optional pre-LayerNorm of CLIP (fp32 in, fp32 out).
 template <int DT, int VPL>
@@ -293,11 +368,23 @@ __global__ void __launch_bounds__(256) pool_kernel(const float *__restrict__ x, 
 
 int vm_resid_layernorm(vm_ctx *ctx, int dtype, float *x32, const uint16_t *delta16, const uint16_t *deltaB16,
                        int write_x, const float *gamma, const float *beta, float eps, uint16_t *out16, int rows, int H,
-                       hipStream_t st, int rstride) {
+                       hipStream_t st, int rstride, int lowreg) {
     constexpr int RPW = 2;
     const int blocks = (rows + 4 * RPW - 1) / (4 * RPW);
     if (H % 256 != 0) return vm_fail(ctx, VM_ERR_UNSUPPORTED, "row width %d", H);
     vm_prof_scope prof(ctx, VM_PROF_LAYERNORM, st);
+    if (lowreg) {   // two-stream mode: the variant that fits beside the persistent GEMM (always the streaming policy)
+        const int blk = (rows + 3) / 4;
+#define RLNL(V)                                                                                                          \
+    if (dtype == VM_F16)                                                                                                 \
+        resid_layernorm_lowreg_kernel<VM_F16, V, true><<<blk, 256, 0, st>>>(x32, delta16, deltaB16, write_x, gamma, beta, eps, out16, rows, H, rstride); \
+    else                                                                                                                 \
+        resid_layernorm_lowreg_kernel<VM_BF16, V, true><<<blk, 256, 0, st>>>(x32, delta16, deltaB16, write_x, gamma, beta, eps, out16, rows, H, rstride)
+        VM_VPL_SWITCH(H, RLNL)
+#undef RLNL
+        VM_LAUNCH_CHECK(ctx);
+        return VM_OK;
+    }
     // rows that together exceed the 32 MiB of L2 several times over stream through with the non-temporal policy
     static int nt_env = -1;
     if (nt_env < 0) {
@@ -370,6 +457,12 @@ struct vm_encoder {
     LayerW *layers;
     int micro_batch;
     int cls_last;   // VIDMEM_CLS_LAST at creation (developer A/B; default 3): see vm_encode's last layer
+    // two-stream mode (VIDMEM_ENC_DUAL=1 at creation, default off): consecutive micro-batch passes of one vm_encode
+    // call alternate between two internal streams, so that the bandwidth-bound LayerNorms of one pass (low-register
+    // build) run beside the matrix-bound GEMMs of the other; see vm_encode
+    int dual;
+    hipStream_t side[2];
+    hipEvent_t ev_fork, ev_join[2];
 };
 
 static int round_up(int x, int a) { return (x + a - 1) / a * a; }
@@ -405,6 +498,22 @@ extern "C" int vm_encoder_create(vm_ctx *ctx, const vm_encoder_desc *desc, const
     e->micro_batch = mb ? atoi(mb) : 0;
     const char *cl = getenv("VIDMEM_CLS_LAST");
     e->cls_last = cl ? atoi(cl) : 3;
+    {
+        const char *du = getenv("VIDMEM_ENC_DUAL");
+        e->dual = du ? atoi(du) : 0;
+        if (e->dual) {
+            hipError_t he = hipSuccess;
+            for (int i = 0; i < 2 && he == hipSuccess; ++i) {
+                he = hipStreamCreateWithFlags(&e->side[i], hipStreamNonBlocking);
+                if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming);
+            }
+            if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
+            if (he != hipSuccess) {
+                delete e;
+                return vm_fail(ctx, VM_ERR_HIP, "two-stream mode: %s", hipGetErrorString(he));
+            }
+        }
+    }
     const size_t H = d.hidden, M = d.mlp;
     // byte sizes in header order
     auto a256 = [](size_t b) { return vm_align_up(b, 256); };
@@ -485,6 +594,13 @@ extern "C" int vm_encoder_create(vm_ctx *ctx, const vm_encoder_desc *desc, const
 
 extern "C" void vm_encoder_destroy(vm_encoder *e) {
     if (!e) return;
+    if (e->dual) {
+        for (int i = 0; i < 2; ++i) {
+            if (e->side[i]) (void)hipStreamDestroy(e->side[i]);
+            if (e->ev_join[i]) (void)hipEventDestroy(e->ev_join[i]);
+        }
+        if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    }
     if (e->blob) (void)hipFree(e->blob);
     delete[] e->layers;
     delete e;
@@ -546,7 +662,9 @@ static Ws carve(const vm_encoder *e, int mb, void *base) {
 
 extern "C" size_t vm_encode_workspace_bytes(const vm_encoder *e, int B) {
     if (!e || B <= 0) return 0;
-    return carve(e, micro_batch_of(e, B), nullptr).bytes;
+    const int mb = micro_batch_of(e, B);
+    const size_t one = carve(e, mb, nullptr).bytes;
+    return (e->dual && B > mb) ? 2 * one : one;   // two-stream mode: one workspace per stream
 }
 
 extern "C" int vm_encode_micro_batch(const vm_encoder *e, int B) { return e && B > 0 ? micro_batch_of(e, B) : 0; }
@@ -557,96 +675,163 @@ extern "C" int vm_encode(vm_encoder *e, const void *patches, int B, void *out_em
     vm_ctx *ctx = e->ctx;
     if (!patches || !out_emb || B <= 0) return vm_fail(ctx, VM_ERR_INVALID, "vm_encode: bad arguments");
     const int mb = micro_batch_of(e, B);
-    const Ws ws = carve(e, mb, workspace);
-    if (!workspace || workspace_bytes < ws.bytes)
-        return vm_fail(ctx, VM_ERR_NOMEM, "vm_encode: workspace %zu < %zu", workspace_bytes, ws.bytes);
+    const Ws ws0 = carve(e, mb, workspace);
+    if (!workspace || workspace_bytes < ws0.bytes)
+        return vm_fail(ctx, VM_ERR_NOMEM, "vm_encode: workspace %zu < %zu", workspace_bytes, ws0.bytes);
     if (((uintptr_t)workspace & 255) || ((uintptr_t)patches & 15) || ((uintptr_t)out_emb & 15))
         return vm_fail(ctx, VM_ERR_INVALID, "vm_encode: workspace must be 256-byte, tensors 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const vm_encoder_desc &d = e->d;
     const int H = d.hidden, T = e->tokens, P = e->patches, dt = d.dtype;
     const int act_epi = d.act == VM_ACT_QUICK_GELU ? EPI_QGELU16 : EPI_GELU16;
-    int rc;
-    for (int b0 = 0; b0 < B; b0 += mb) {
-        const int nb = B - b0 < mb ? B - b0 : mb;
-        const int rows = nb * T;
-        GemmArgs g;
-        int g_head_major = 0, g_hm_rows = 0, g_hm_stride = 0;
-        // VIDMEM_CLS_LAST, read when the encoder is created (developer A/B): bit 0 = projection / LN2 / MLP of the last
-        // layer on the CLS rows only, bit 1 = also only the CLS rows' queries and query tile in its attention; 0 =
-        // everything on every row
-        const int cls_env = e->cls_last;
-        const bool cls_only = (cls_env & 1) != 0;
-        auto gemm16 = [&](const uint16_t *X, int ldx, const uint16_t *W, const float *bias, uint16_t *out, int M, int N,
-                          int K, int epi, int cat, int ldo = 0) {
-            memset(&g, 0, sizeof(g));
-            g.X = X; g.W = W; g.bias = bias; g.out16 = out;
-            g.M = M; g.N = N; g.K = K; g.ldx = ldx; g.ldo = ldo ? ldo : N; g.prof_cat = cat; g.head_major = g_head_major;
-            g.hm_rows = g_hm_rows; g.hm_stride = g_hm_stride;
-            return vm_gemm(ctx, dt, g, epi, st);
-        };
-        // patch embedding: [nb*P, patch_k] x [H, patch_k]^T (+bias) -> 16-bit rows; then x32 = rows + pos (+cls) [+pre-LN]
-        if ((rc = gemm16((const uint16_t *)patches + (size_t)b0 * P * e->patch_k, e->patch_k, e->patch_w, e->patch_b,
-                         ws.d16, nb * P, H, e->patch_k, EPI_DELTA16, VM_PROF_GEMM_PATCH)) != VM_OK) return rc;
-        if ((rc = vm_embed(ctx, dt, ws.d16, e->cls, e->pos, e->pre_g, e->pre_b, d.ln_eps, d.pre_ln, ws.x32, nb, T, H,
-                           st)) != VM_OK) return rc;
-        // Branch outputs not yet folded into x32: the projection's (ws.d16) and FC2's (ws.e16) of the PREVIOUS layer.
-        const uint16_t *pend_proj = nullptr, *pend_fc2 = nullptr;
-        for (int l = 0; l < d.layers; ++l) {
-            const LayerW &w = e->layers[l];
-            // x32 += proj(l-1) + fc2(l-1), written back once; a16 = LN1(x32)
-            // (last layer: only the CLS rows' folded sums are read again - by LN2 and the pool - so only they are written)
-            const int fold = pend_proj == nullptr ? 0 : (l == d.layers - 1 && cls_only && T > 1 ? T : 1);
-            if ((rc = vm_resid_layernorm(ctx, dt, ws.x32, pend_proj, pend_fc2, fold, w.ln1_g, w.ln1_b,
-                                         d.ln_eps, ws.a16, rows, H, st)) != VM_OK) return rc;
-            const bool last_cls = l == d.layers - 1 && cls_only;
-            g_head_major = 1;  // q/k/v of one head as contiguous [rows, 64] blocks: attention streams whole KiB
-            if (last_cls && (cls_env & 2)) {
-                // last layer: keys and values of every row, but only the CLS rows' queries (see below): the K / V
-                // weight rows [H, 3H) write the k and v blocks, then a GEMM over the nb CLS rows (row stride T) writes
-                // each head's query into row b*T of its q block
-                rc = gemm16(ws.a16, H, w.qkv_w + (size_t)H * H, w.qkv_b + H, ws.qkv16 + (size_t)d.heads * rows * 64, rows,
-                            2 * H, H, EPI_STORE16, VM_PROF_GEMM_QKV);
-                if (rc == VM_OK) {
-                    g_hm_rows = rows;
-                    g_hm_stride = T;
-                    rc = gemm16(ws.a16, T * H, w.qkv_w, w.qkv_b, ws.qkv16, nb, H, H, EPI_STORE16, VM_PROF_GEMM_CLS);
-                    g_hm_rows = g_hm_stride = 0;
-                }
-            } else {
-                rc = gemm16(ws.a16, H, w.qkv_w, w.qkv_b, ws.qkv16, rows, 3 * H, H, EPI_STORE16, VM_PROF_GEMM_QKV);
-            }
-            g_head_major = 0;
-            if (rc != VM_OK) return rc;
-            if ((rc = vm_attention(ctx, dt, ws.qkv16, ws.a16, nb, T, d.heads, st, last_cls && (cls_env & 2) ? 1 : 0)) != VM_OK)
-                return rc;
-            if (last_cls) {
-                // LAST layer: the embedding is pooled from the CLS row alone (vm_pool), and behind the attention every
-                // row depends only on itself - so projection, LN2, FC1 and FC2 run on the nb CLS rows, addressed in
-                // place with a row stride of T rows (GEMM ldx / ldo, LN rstride).  The other rows' branch outputs were
-                // never read by anything; the CLS rows get the same values bit for bit (every GEMM tiling accumulates
-                // an output in the same MFMA order).  6.2 % of ViT-B/16's FLOPs, 3.5 % of CLIP-L/14-336's.
-                const int TH = T * H;
-                if ((rc = gemm16(ws.a16, TH, w.proj_w, w.proj_b, ws.d16, nb, H, H, EPI_DELTA16, VM_PROF_GEMM_CLS, TH)) != VM_OK) return rc;
-                if ((rc = vm_resid_layernorm(ctx, dt, ws.x32, ws.d16, nullptr, 0, w.ln2_g, w.ln2_b, d.ln_eps, ws.a16, nb,
-                                             H, st, T)) != VM_OK) return rc;
-                if ((rc = gemm16(ws.a16, TH, w.fc1_w, w.fc1_b, ws.mlp16, nb, d.mlp, H, act_epi, VM_PROF_GEMM_CLS)) != VM_OK) return rc;
-                if ((rc = gemm16(ws.mlp16, d.mlp, w.fc2_w, w.fc2_b, ws.e16, nb, H, d.mlp, EPI_DELTA16, VM_PROF_GEMM_CLS, TH)) != VM_OK) return rc;
-            } else {
-                if ((rc = gemm16(ws.a16, H, w.proj_w, w.proj_b, ws.d16, rows, H, H, EPI_DELTA16, VM_PROF_GEMM_RESID)) != VM_OK) return rc;
-                // a16 = LN2(x32 + proj(l)); x32 itself is NOT rewritten here: the next LN1 (or the pool) folds both
-                if ((rc = vm_resid_layernorm(ctx, dt, ws.x32, ws.d16, nullptr, 0, w.ln2_g, w.ln2_b, d.ln_eps, ws.a16, rows,
-                                             H, st)) != VM_OK) return rc;
-                if ((rc = gemm16(ws.a16, H, w.fc1_w, w.fc1_b, ws.mlp16, rows, d.mlp, H, act_epi, VM_PROF_GEMM_ACT)) != VM_OK) return rc;
-                if ((rc = gemm16(ws.mlp16, d.mlp, w.fc2_w, w.fc2_b, ws.e16, rows, H, d.mlp, EPI_DELTA16, VM_PROF_GEMM_RESID)) != VM_OK) return rc;
-            }
-            pend_proj = ws.d16;
-            pend_fc2 = ws.e16;
-        }
-        uint16_t *dst = (uint16_t *)out_emb + (size_t)b0 * e->out_dim;
-        if ((rc = vm_pool(ctx, dt, ws.x32, pend_proj, pend_fc2, e->ln_g, e->ln_b, d.ln_eps, e->proj_w, d.proj_dim,
-                          l2_normalise, dst, nb, T, H, st)) != VM_OK)
-            return rc;
+    // VIDMEM_CLS_LAST, read when the encoder is created (developer A/B): bit 0 = projection / LN2 / MLP of the last
+    // layer on the CLS rows only, bit 1 = also only the CLS rows' queries and query tile in its attention; 0 =
+    // everything on every row
+    const int cls_env = e->cls_last;
+    const bool cls_only = (cls_env & 1) != 0;
+
+    // Two-stream mode (e->dual, VIDMEM_ENC_DUAL=1 when the encoder is created; default off).  Consecutive micro-batch
+    // passes of a call alternate between two internal streams (fork behind the caller's stream, join before returning;
+    // one workspace per stream) and the residual + LayerNorm passes use their low-register build - 58 VGPRs, no LDS:
+    // the only kernel of the encoder that is admitted NEXT TO the persistent GEMM, which leaves 64 VGPRs per SIMD and
+    // 4 KiB of LDS free.  Measured (alternating A/B, embeddings bit-identical): ViT-B/16 fp16
+    // 25.7 k -> 26.8 k frames/s (+4.3 %), CLIP-L/14-336 bf16 2,615 -> 2,703 (+3.3 %); with the ordinary LayerNorm on
+    // two streams +-0; with every matrix kernel of both passes on ONE stream and only the LayerNorms on a side stream
+    // between events (tools/experiments/encoder_kernel_granularity_pipeline.patch) -1.3 %: the GEMM launches stretch
+    // by more than the LayerNorm time they cover.  It is off by default because HIP-event (and rocprofv3) kernel
+    // durations then include the time a kernel waits for the other stream's GEMM to leave the CUs: per-kernel
+    // rooflines can no longer be read from them.
+    struct Pass {
+        int b0, nb, rows;
+        Ws ws;
+        const uint16_t *pend_proj, *pend_fc2;   // branch outputs not yet folded into x32 (previous layer's)
+    };
+    const bool dual = e->dual && B > mb && workspace_bytes >= 2 * ws0.bytes;
+    const Ws ws1 = dual ? carve(e, mb, (char *)workspace + ws0.bytes) : ws0;
+    hipStream_t st0 = st;
+    int rc = VM_OK;
+    if (dual) {   // fork: both internal streams start behind everything queued on the caller's stream
+        VM_HIP(ctx, hipEventRecord(e->ev_fork, st0));
+        for (int i = 0; i < 2; ++i) VM_HIP(ctx, hipStreamWaitEvent(e->side[i], e->ev_fork, 0));
     }
+    GemmArgs g;
+    int g_head_major = 0, g_hm_rows = 0, g_hm_stride = 0;
+    auto gemm16 = [&](const uint16_t *X, int ldx, const uint16_t *W, const float *bias, uint16_t *out, int M, int N,
+                      int K, int epi, int cat, int ldo = 0) {
+        memset(&g, 0, sizeof(g));
+        g.X = X; g.W = W; g.bias = bias; g.out16 = out;
+        g.M = M; g.N = N; g.K = K; g.ldx = ldx; g.ldo = ldo ? ldo : N; g.prof_cat = cat; g.head_major = g_head_major;
+        g.hm_rows = g_hm_rows; g.hm_stride = g_hm_stride;
+        return vm_gemm(ctx, dt, g, epi, st);
+    };
+    // ---- the stages of one pass ----
+    auto embed = [&](Pass &p) -> int {
+        // patch embedding: [nb*P, patch_k] x [H, patch_k]^T (+bias) -> 16-bit rows; then x32 = rows + pos (+cls) [+pre-LN]
+        int r = gemm16((const uint16_t *)patches + (size_t)p.b0 * P * e->patch_k, e->patch_k, e->patch_w, e->patch_b,
+                       p.ws.d16, p.nb * P, H, e->patch_k, EPI_DELTA16, VM_PROF_GEMM_PATCH);
+        if (r != VM_OK) return r;
+        p.pend_proj = p.pend_fc2 = nullptr;
+        return vm_embed(ctx, dt, p.ws.d16, e->cls, e->pos, e->pre_g, e->pre_b, d.ln_eps, d.pre_ln, p.ws.x32, p.nb, T, H, st);
+    };
+    auto ln1 = [&](Pass &p, int l) -> int {
+        // x32 += proj(l-1) + fc2(l-1), written back once; a16 = LN1(x32)
+        // (last layer: only the CLS rows' folded sums are read again - by LN2 and the pool - so only they are written)
+        const LayerW &w = e->layers[l];
+        const int fold = p.pend_proj == nullptr ? 0 : (l == d.layers - 1 && cls_only && T > 1 ? T : 1);
+        return vm_resid_layernorm(ctx, dt, p.ws.x32, p.pend_proj, p.pend_fc2, fold, w.ln1_g, w.ln1_b, d.ln_eps, p.ws.a16,
+                                  p.rows, H, st, 1, dual ? 1 : 0);
+    };
+    auto attn_block = [&](Pass &p, int l) -> int {   // QKV, attention, projection
+        const LayerW &w = e->layers[l];
+        const Ws &ws = p.ws;
+        const int rows = p.rows, nb = p.nb;
+        const bool last_cls = l == d.layers - 1 && cls_only;
+        int r;
+        g_head_major = 1;  // q/k/v of one head as contiguous [rows, 64] blocks: attention streams whole KiB
+        if (last_cls && (cls_env & 2)) {
+            // last layer: keys and values of every row, but only the CLS rows' queries (see below): the K / V
+            // weight rows [H, 3H) write the k and v blocks, then a GEMM over the nb CLS rows (row stride T) writes
+            // each head's query into row b*T of its q block
+            r = gemm16(ws.a16, H, w.qkv_w + (size_t)H * H, w.qkv_b + H, ws.qkv16 + (size_t)d.heads * rows * 64, rows,
+                       2 * H, H, EPI_STORE16, VM_PROF_GEMM_QKV);
+            if (r == VM_OK) {
+                g_hm_rows = rows;
+                g_hm_stride = T;
+                r = gemm16(ws.a16, T * H, w.qkv_w, w.qkv_b, ws.qkv16, nb, H, H, EPI_STORE16, VM_PROF_GEMM_CLS);
+                g_hm_rows = g_hm_stride = 0;
+            }
+        } else {
+            r = gemm16(ws.a16, H, w.qkv_w, w.qkv_b, ws.qkv16, rows, 3 * H, H, EPI_STORE16, VM_PROF_GEMM_QKV);
+        }
+        g_head_major = 0;
+        if (r != VM_OK) return r;
+        if ((r = vm_attention(ctx, dt, ws.qkv16, ws.a16, nb, T, d.heads, st, last_cls && (cls_env & 2) ? 1 : 0)) != VM_OK)
+            return r;
+        if (last_cls) {
+            // LAST layer: the embedding is pooled from the CLS row alone (vm_pool), and behind the attention every
+            // row depends only on itself - so projection, LN2, FC1 and FC2 run on the nb CLS rows, addressed in
+            // place with a row stride of T rows (GEMM ldx / ldo, LN rstride).  The other rows' branch outputs were
+            // never read by anything; the CLS rows get the same values bit for bit (every GEMM tiling accumulates
+            // an output in the same MFMA order).  6.2 % of ViT-B/16's FLOPs, 3.5 % of CLIP-L/14-336's.
+            const int TH = T * H;
+            return gemm16(ws.a16, TH, w.proj_w, w.proj_b, ws.d16, nb, H, H, EPI_DELTA16, VM_PROF_GEMM_CLS, TH);
+        }
+        return gemm16(ws.a16, H, w.proj_w, w.proj_b, ws.d16, rows, H, H, EPI_DELTA16, VM_PROF_GEMM_RESID);
+    };
+    auto ln2 = [&](Pass &p, int l) -> int {
+        // a16 = LN2(x32 + proj(l)); x32 itself is NOT rewritten here: the next LN1 (or the pool) folds both
+        const LayerW &w = e->layers[l];
+        const bool last_cls = l == d.layers - 1 && cls_only;
+        return vm_resid_layernorm(ctx, dt, p.ws.x32, p.ws.d16, nullptr, 0, w.ln2_g, w.ln2_b, d.ln_eps, p.ws.a16,
+                                  last_cls ? p.nb : p.rows, H, st, last_cls ? T : 1, dual && !last_cls ? 1 : 0);
+    };
+    auto mlp_block = [&](Pass &p, int l) -> int {   // FC1 (+activation), FC2
+        const LayerW &w = e->layers[l];
+        const Ws &ws = p.ws;
+        const bool last_cls = l == d.layers - 1 && cls_only;
+        int r;
+        if (last_cls) {
+            const int TH = T * H;
+            if ((r = gemm16(ws.a16, TH, w.fc1_w, w.fc1_b, ws.mlp16, p.nb, d.mlp, H, act_epi, VM_PROF_GEMM_CLS)) != VM_OK) return r;
+            r = gemm16(ws.mlp16, d.mlp, w.fc2_w, w.fc2_b, ws.e16, p.nb, H, d.mlp, EPI_DELTA16, VM_PROF_GEMM_CLS, TH);
+        } else {
+            if ((r = gemm16(ws.a16, H, w.fc1_w, w.fc1_b, ws.mlp16, p.rows, d.mlp, H, act_epi, VM_PROF_GEMM_ACT)) != VM_OK) return r;
+            r = gemm16(ws.mlp16, d.mlp, w.fc2_w, w.fc2_b, ws.e16, p.rows, H, d.mlp, EPI_DELTA16, VM_PROF_GEMM_RESID);
+        }
+        p.pend_proj = ws.d16;
+        p.pend_fc2 = ws.e16;
+        return r;
+    };
+    auto pool = [&](Pass &p) -> int {
+        uint16_t *dst = (uint16_t *)out_emb + (size_t)p.b0 * e->out_dim;
+        return vm_pool(ctx, dt, p.ws.x32, p.pend_proj, p.pend_fc2, e->ln_g, e->ln_b, d.ln_eps, e->proj_w, d.proj_dim,
+                       l2_normalise, dst, p.nb, T, H, st);
+    };
+#define VM_TRY(x) do { if ((rc = (x)) != VM_OK) return rc; } while (0)
+    int pass = 0;
+    for (int b0 = 0; b0 < B; ++pass) {
+        Pass A;
+        A.b0 = b0;
+        A.nb = B - b0 < mb ? B - b0 : mb;
+        A.rows = A.nb * T;
+        A.ws = dual && (pass & 1) ? ws1 : ws0;
+        st = dual ? e->side[pass & 1] : st0;    // the stage lambdas launch on `st`
+        VM_TRY(embed(A));
+        for (int l = 0; l < d.layers; ++l) {
+            VM_TRY(ln1(A, l));
+            VM_TRY(attn_block(A, l));
+            VM_TRY(ln2(A, l));
+            VM_TRY(mlp_block(A, l));
+        }
+        VM_TRY(pool(A));
+        b0 += A.nb;
+    }
+    if (dual) {   // join: the caller's stream continues behind both
+        for (int i = 0; i < 2; ++i) {
+            VM_HIP(ctx, hipEventRecord(e->ev_join[i], e->side[i]));
+            VM_HIP(ctx, hipStreamWaitEvent(st0, e->ev_join[i], 0));
+        }
+    }
+#undef VM_TRY
     return VM_OK;
 }

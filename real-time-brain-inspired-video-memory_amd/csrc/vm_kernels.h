@@ -46,7 +46,7 @@ int vm_attention(vm_ctx *ctx, int dtype, const uint16_t *qkv, uint16_t *ctx_out,
 // rstride: row r of the pass lives at row r * rstride of every array (1: dense; tokens per frame: the CLS rows only)
 int vm_resid_layernorm(vm_ctx *ctx, int dtype, float *x32, const uint16_t *delta16, const uint16_t *deltaB16,
                        int write_x, const float *gamma, const float *beta, float eps, uint16_t *out16, int rows, int H,
-                       hipStream_t st, int rstride = 1);
+                       hipStream_t st, int rstride = 1, int lowreg = 0);
 // x32[frame*T + tok] = (tok ? patch16[frame*(T-1) + tok-1] : cls) + pos[tok], then the optional pre-LayerNorm
 int vm_embed(vm_ctx *ctx, int dtype, const uint16_t *patch16, const float *cls, const float *pos, const float *pre_g,
              const float *pre_b, float eps, int pre_ln, float *x32, int B, int T, int H, hipStream_t st);

@@ -251,6 +251,31 @@ def test_last_layer_on_cls_rows_is_invisible(monkeypatch, dtype, image, patch, h
     assert torch.equal(_encoder(one, w1, dtype).embed_frames(frames[:5]), full1.embed_frames(frames[:5]))
 
 
+@pytest.mark.parametrize("name,dtype,mbatch,n", [("vit_b16_224", "f16", 64, 200), ("clip_l14_336", "bf16", 28, 70)])
+def test_two_stream_mode_is_invisible(monkeypatch, name, dtype, mbatch, n):
+    """VIDMEM_ENC_DUAL=1 (read when the encoder is created): consecutive micro-batch passes of a call alternate between
+    two internal streams with a workspace each, and the LayerNorms run their low-register build.  Embeddings must equal
+    the single-stream encoder's bit for bit - an even and an odd number of passes, a ragged last pass, and calls of one
+    pass (where the mode does nothing) in between."""
+    from vidmem import synthetic as syn
+    spec = dict(V.SPECS[name], layers=3)
+    w = syn.encoder_weights(spec, seed=17)
+    monkeypatch.setenv("VIDMEM_MICROBATCH", str(mbatch))
+    plain = _encoder(spec, w, dtype)
+    monkeypatch.setenv("VIDMEM_ENC_DUAL", "1")
+    dual = _encoder(spec, w, dtype)
+    monkeypatch.delenv("VIDMEM_ENC_DUAL")
+    monkeypatch.delenv("VIDMEM_MICROBATCH")
+    assert dual.workspace_bytes(n) == 2 * plain.workspace_bytes(n) and dual.workspace_bytes(3) == plain.workspace_bytes(3)
+    S = spec["image"]
+    frames = torch.from_numpy(syn.frames_u8(5, n, S, S)).cuda()
+    for count in (n, 2 * mbatch, 3, 3 * mbatch - 5):          # 4 passes (ragged) / 2 / 1 / 3 (ragged)
+        want = plain.embed_frames(frames[:count])
+        got = dual.embed_frames(frames[:count])
+        assert torch.isfinite(want.float()).all()
+        assert torch.equal(got, want), count
+
+
 @pytest.mark.parametrize("name,dtype,n", [("vit_b16_224", "f16", 500), ("clip_l14_336", "bf16", 120)])
 def test_bench_size_batches_take_the_big_kernels_and_agree(name, dtype, n):
     """BASELINE-size micro-batches (441 ViT-B frames / 112 CLIP-L frames per pass) run the persistent 256x256 GEMM

@@ -1,0 +1,32 @@
+"""Developer probe: vm_encode's two-stream mode (VIDMEM_ENC_DUAL=1, read when the encoder is created) against the
+single-stream one: embeddings bit for bit, frames/s alternating A/B.  dual_probe.py [frames=880] [arch] [dtype]"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, vidmem
+from vidmem import specs, synthetic as syn
+from vidmem.encoder import FrameEncoder
+F = int(sys.argv[1]) if len(sys.argv) > 1 else 880
+arch = sys.argv[2] if len(sys.argv) > 2 else "vit_b16_224"
+dtype = sys.argv[3] if len(sys.argv) > 3 else "f16"
+spec = specs.SPECS[arch]
+w = syn.encoder_weights(spec, seed=42)
+encs = {}
+MODES = sys.argv[4].split(",") if len(sys.argv) > 4 else ["0", "1"]
+for mode in MODES:
+    os.environ["VIDMEM_ENC_DUAL"] = mode
+    encs[mode] = FrameEncoder(spec, w, dtype)
+S = spec["image"]
+fr = torch.randint(0, 256, (F, S, S, 3), device="cuda", dtype=torch.uint8)
+out = {m: e.embed_frames(fr) for m, e in encs.items()}
+torch.cuda.synchronize()
+print("bit-identical:", all(torch.equal(out[MODES[0]], o) for o in out.values()))
+for rep in range(3):
+    for m in MODES:
+        e = encs[m]
+        for _ in range(2): e.embed_frames(fr)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(6): e.embed_frames(fr)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 6
+        print(f"dual={m}: {F} frames in {dt*1e3:.2f} ms = {F/dt:.0f} frames/s", flush=True)
