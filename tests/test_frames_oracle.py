@@ -113,3 +113,45 @@ def test_extractor_sources_and_json_shape(tmp_path, monkeypatch):
     assert set(d["results"][0]) >= {"time", "content", "chunk_idx", "processing_time"}  # vlm_extractor.py:66-71
     assert d["results"][2]["embedding_rows"] == list(range(20, 30)) and d["results"][1]["time"] == "00:01-00:02"
     assert ex._stager.staged == 3 and ex._stager.shape == (16, 8, 8, 3)   # one staging per chunk, sized once
+
+
+def test_cv2_source_branch_with_a_stand_in_module(tmp_path, monkeypatch):
+    """``open_source`` on a real video path goes through ``_Cv2Source`` (cv2.VideoCapture + CAP_PROP_POS_FRAMES seeks,
+    src/pipeline/vlm_extractor.py:32-39,108-111).  OpenCV is not installed in the build image, so a stand-in module with
+    the four calls the class makes is injected: frame count / fps come from the capture, ``read(idx)`` seeks then reads,
+    an unreadable frame is ``None`` (dropped by the chunk reader, :111), ``release`` reaches the capture."""
+    import sys
+    import types
+    from vidmem import extractor as X
+    frames = np.arange(7 * 4 * 6 * 3, dtype=np.uint8).reshape(7, 4, 6, 3)
+    log = []
+
+    class FakeCapture:
+        def __init__(self, path):
+            log.append(("open", path))
+            self.pos = 0
+
+        def get(self, prop):
+            return {5: 25.0, 7: float(len(frames))}[prop]
+
+        def set(self, prop, value):
+            assert prop == 1
+            self.pos = int(value)
+
+        def read(self):
+            ok = 0 <= self.pos < len(frames) and self.pos != 3        # frame 3 is unreadable
+            return (ok, frames[self.pos].copy() if ok else None)
+
+        def release(self):
+            log.append(("release",))
+
+    fake = types.SimpleNamespace(VideoCapture=FakeCapture, CAP_PROP_POS_FRAMES=1, CAP_PROP_FPS=5, CAP_PROP_FRAME_COUNT=7)
+    monkeypatch.setitem(sys.modules, "cv2", fake)
+    src = X.open_source(str(tmp_path / "clip.mp4"))
+    assert isinstance(src, X._Cv2Source) and src.fps == 25.0 and src.total == 7
+    assert np.array_equal(src.read(5), frames[5]) and src.read(3) is None and src.read(9) is None
+    ex = X.FrameEmbeddingExtractor.__new__(X.FrameEmbeddingExtractor)     # only the chunk reader is exercised
+    got = ex._read_chunk(src, [0, 3, 6])
+    assert len(got) == 2 and np.array_equal(got[1], frames[6])             # the unreadable pick is dropped
+    src.release()
+    assert log == [("open", str(tmp_path / "clip.mp4")), ("release",)]
