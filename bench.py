@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--chunks-per-step", type=int, default=55,
-                    help="chunks of 16 frames encoded per step per GPU (55 chunks = 880 frames = 2 encoder passes of 440)")
+                    help="chunks of 16 frames encoded per step per GPU (55 chunks = 880 frames = one encoder pass)")
     ap.add_argument("--memory-rows", type=int, default=None,
                     help="rows of the memory shard per GPU (default: 100,000 = BASELINE configs[1] on one GPU; "
                          "1,048,576 = BASELINE configs[3], 8 M rows over 8 GPUs, when --gpus > 1)")
@@ -55,8 +55,8 @@ def parse():
     ap.add_argument("--knn-rows", type=int, default=1_000_000)
     ap.add_argument("--no-streaming", action="store_true")
     ap.add_argument("--no-c3", action="store_true", help="skip the CLIP-ViT-L/14-336 bf16 leg (BASELINE configs[2])")
-    ap.add_argument("--c3-frames", type=int, default=2048 + 112, help="frames per timing of the C3 leg (rounded down "
-                    "to whole 113-frame encoder passes; BASELINE configs[2] names 32k frames)")
+    ap.add_argument("--c3-frames", type=int, default=2048 + 224, help="frames per timing of the C3 leg (rounded down "
+                    "to whole encoder passes of 224 frames; BASELINE configs[2] names 32k frames)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI); gloo only to rehearse N>1 on one GPU")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--dry-run", action="store_true", help="launcher self-test: rendezvous + barrier on the CPU (gloo), "
@@ -337,10 +337,17 @@ def main():
 
     # ---- A/B beside the headline: the same steps through an encoder created in its two-stream mode -----------------
     two_stream = None
-    if rank == 0 and world == 1 and not args.no_two_stream and F > mb_frames:
+    if rank == 0 and world == 1 and not args.no_two_stream and F >= 32:
         os.environ["VIDMEM_ENC_DUAL"] = "1"
+        had_mb = os.environ.get("VIDMEM_MICROBATCH")
+        if F <= mb_frames:      # the mode works on consecutive passes of one call: two passes of half the step
+            os.environ["VIDMEM_MICROBATCH"] = str((F + 1) // 2)
         enc2 = FrameEncoder(spec, weights, dtype="f16", device=local_rank)
         del os.environ["VIDMEM_ENC_DUAL"]
+        if had_mb is None:
+            os.environ.pop("VIDMEM_MICROBATCH", None)
+        else:
+            os.environ["VIDMEM_MICROBATCH"] = had_mb
         main_enc = enc
 
         def step2(i):
@@ -726,7 +733,7 @@ def main():
         spec3 = specs.CLIP_L14_336
         enc3 = FrameEncoder(spec3, syn.encoder_weights(spec3, seed=42), dtype="bf16", device=local_rank)
         g3 = torch.Generator(device=dev).manual_seed(4321)
-        mb3 = enc3.micro_batch(args.c3_frames)                                # 112 frames per encoder pass
+        mb3 = enc3.micro_batch(args.c3_frames)                                # 224 frames per encoder pass
         F3 = args.c3_frames // mb3 * mb3                                      # >= 2048 frames per timing
         fr3 = torch.randint(0, 256, (F3, 336, 336, 3), generator=g3, device=dev, dtype=torch.uint8)
         M3, D3, k3 = 1_000_000, 1024, 20

@@ -617,11 +617,12 @@ static int micro_batch_of(const vm_encoder *e, int B) {
     // CLIP-L/14-336 (T=577, hidden 1024): 64 x 4 = 256 tiles -> 28 frames per round.
     int mb = e->micro_batch;
     if (mb <= 0) {
-        // 4 rounds of tiles per launch for the narrowest GEMM: fewer, longer launches amortise the ~6 us of ramp and
-        // tail each of the ~85 kernels of a pass pays (measured +3 % over 1 round); 1.5 GB of workspace is nothing
+        // 8 rounds of tiles per launch for the narrowest GEMM: fewer, longer launches amortise the ~6 us of ramp and
+        // tail each of the ~85 kernels of a pass pays (measured: 4 rounds +3 % over 1 round; 8 rounds - the bench's 880
+        // frames in ONE pass - another +1.8 %, 24.4 k -> 24.9 k frames/s on one box); 3.2 GB of workspace is nothing
         // next to 288 GB of HBM
         const int col_tiles = e->d.hidden / 256;
-        const int row_tiles = 4 * (e->ctx->num_cus / col_tiles);
+        const int row_tiles = 8 * (e->ctx->num_cus / col_tiles);
         mb = row_tiles * 256 / e->tokens;
         if (mb < 1) mb = 1;
         // Sequences past 208 tokens run ONE attention workgroup per (frame, head) and CU (attention.hip, long kernel):
