@@ -619,10 +619,10 @@ int launch_long(vm_ctx *ctx, const uint16_t *qkv, uint16_t *out, int B, int T, i
 #define VM_PAIR_GO(NWV)                                                                                              \
     {                                                                                                                \
         auto kern = attention_pair_kernel<DT, NT, EXACT, NWV>;                                                       \
-        static bool attr_set = false;                                                                                \
-        if (!attr_set) {                                                                                             \
+        static unsigned long long attr_set = 0; /* one bit per device */                                              \
+        if (!((attr_set >> (ctx->device & 63)) & 1ull)) {                                                                                             \
             VM_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-            attr_set = true;                                                                                         \
+            attr_set |= 1ull << (ctx->device & 63);                                                                                         \
         }                                                                                                            \
         kern<<<B * heads, NWV * 64, lds, st>>>(qkv, out, T, heads, ql);                                              \
     }
@@ -632,18 +632,18 @@ int launch_long(vm_ctx *ctx, const uint16_t *qkv, uint16_t *out, int B, int T, i
 #undef VM_PAIR_GO
     } else if (online_env) {
         auto kern = attention_long_kernel<DT, NT, EXACT, 16, true>;
-        static bool attr_set = false;
-        if (!attr_set) {
+        static unsigned long long attr_set = 0;   // one bit per device
+        if (!((attr_set >> (ctx->device & 63)) & 1ull)) {
             VM_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set = true;
+            attr_set |= 1ull << (ctx->device & 63);
         }
         kern<<<B * heads, 1024, lds, st>>>(qkv, out, T, heads, qt_lim < NT ? qt_lim : NT);
     } else {
         auto kern = attention_long_kernel<DT, NT, EXACT, 16, false>;
-        static bool attr_set = false;
-        if (!attr_set) {
+        static unsigned long long attr_set = 0;   // one bit per device
+        if (!((attr_set >> (ctx->device & 63)) & 1ull)) {
             VM_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set = true;
+            attr_set |= 1ull << (ctx->device & 63);
         }
         kern<<<B * heads, 1024, lds, st>>>(qkv, out, T, heads, qt_lim < NT ? qt_lim : NT);
     }
@@ -798,10 +798,10 @@ template <int DT, int NT, bool EXACT, int CW>
 int launch_stream_cw(vm_ctx *ctx, const uint16_t *qkv, uint16_t *out, int B, int T, int heads, hipStream_t st, int qt_lim) {
     const size_t lds = (size_t)NT * 16 * 128 * 6;
     auto kern = attention_stream_kernel<DT, NT, EXACT, CW>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_set = 0;   // one bit per device
+    if (!((attr_set >> (ctx->device & 63)) & 1ull)) {
         VM_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_set |= 1ull << (ctx->device & 63);
     }
     const int items = B * heads;
     const int grid = items < ctx->num_cus ? items : ctx->num_cus;
@@ -829,10 +829,10 @@ template <int DT, int NT, bool EXACT, int OCC = (NT <= 13 ? 2 : 1)>
 int launch(vm_ctx *ctx, const uint16_t *qkv, uint16_t *out, int B, int T, int heads, hipStream_t st, int qt_lim) {
     const size_t lds = (size_t)NT * 16 * 128 * 2;
     auto kern = attention_kernel<DT, NT, EXACT, OCC>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_set = 0;   // one bit per device
+    if (!((attr_set >> (ctx->device & 63)) & 1ull)) {
         VM_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_set |= 1ull << (ctx->device & 63);
     }
     vm_prof_scope prof(ctx, VM_PROF_ATTENTION, st);
     kern<<<B * heads, 256, lds, st>>>(qkv, out, T, heads, qt_lim < NT ? qt_lim : NT);

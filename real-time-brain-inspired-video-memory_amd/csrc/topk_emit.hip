@@ -521,11 +521,11 @@ int launch_emit(vm_memory *m, const void *queries, int Q, const float *thr_s, co
     constexpr int STAGES = KS <= 6 ? 3 : 2;
     const size_t lds = (size_t)STAGES * (EM_ROWS * 2 * D + 256) + (size_t)EM_WAVES * EM_WBUF * 12;
     auto kern = topk_emit_kernel<DT, KS, NG, DEEP>;
-    static bool attr = false;
-    if (!attr) {
+    static unsigned long long attr = 0;   // one bit per device: the attribute belongs to the (kernel, device) pair
+    if (!((attr >> (m->ctx->device & 63)) & 1ull)) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return vm_fail(m->ctx, VM_ERR_HIP, "emit LDS opt-in %zu: %s", lds, hipGetErrorString(e));
-        attr = true;
+        attr |= 1ull << (m->ctx->device & 63);
     }
     const int nsuper = (Q + EM_QPB * NG - 1) / (EM_QPB * NG);
     int nbx = m->ctx->num_cus / nsuper;

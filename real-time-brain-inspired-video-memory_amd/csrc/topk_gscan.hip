@@ -169,12 +169,6 @@ __global__ void __launch_bounds__(512, 1) topk_gscan_kernel(GscanArgs g) {
 
     f32x4 acc[8][4];
     vec8 af[4][2], bf[4][2];
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    };
     auto read_a = [&](const char *buf, int half) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -193,16 +187,31 @@ __global__ void __launch_bounds__(512, 1) topk_gscan_kernel(GscanArgs g) {
     };
     // acc[i][j][e] = <memory row (panel + 128 wr + 16 i + 4 h + e), query (q0 + 64 wc + 16 j + r16)>: rows are the
     // MFMA A operand, so the four scores of a lane share one query (one cut) - as in the emit scan
-    auto mma = [&](int ahalf, int bhalf) {
+    // first: the first K-step of a tile starts from C = 0 inside the MFMA (inline constant) instead of 128 cleared
+    // registers per wave and tile (zero_acc: ~2 % of a tile's time in vector moves)
+    auto mma = [&](int ahalf, int bhalf, bool first) {
         __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
+        if (first) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[ahalf * 4 + i][bhalf * 2 + j] =
-                        E::mfma16(af[i][s], bf[bhalf * 2 + j][s], acc[ahalf * 4 + i][bhalf * 2 + j]);
+                        E::mfma16(af[i][0], bf[bhalf * 2 + j][0], f32x4{0.f, 0.f, 0.f, 0.f});
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[ahalf * 4 + i][bhalf * 2 + j] =
+                        E::mfma16(af[i][0], bf[bhalf * 2 + j][0], acc[ahalf * 4 + i][bhalf * 2 + j]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[ahalf * 4 + i][bhalf * 2 + j] =
+                    E::mfma16(af[i][1], bf[bhalf * 2 + j][1], acc[ahalf * 4 + i][bhalf * 2 + j]);
         __builtin_amdgcn_s_setprio(0);
     };
 #define GS_BAR() __builtin_amdgcn_s_barrier()
@@ -308,7 +317,6 @@ __global__ void __launch_bounds__(512, 1) topk_gscan_kernel(GscanArgs g) {
     wait_vmcnt<0>();
     GS_BAR();
     if (wr == 1) GS_BAR();  // wave row 1 runs one barrier behind wave row 0
-    zero_acc();
 
     // The K-tile stream of gemm256p_kernel: LDS-DMA of K-tile kt + 1 spread over the four phases of K-tile kt, issue
     // order Aa0, Bb0, Bb1, Aa1, each region retired by a counted wait before the first barrier of the phase that
@@ -346,7 +354,7 @@ __global__ void __launch_bounds__(512, 1) topk_gscan_kernel(GscanArgs g) {
             }
             GS_BAR();
             GS_LGKM0();
-            mma(0, 0);
+            mma(0, 0, kt == 0);
             GS_BAR();
             // phase 2
             read_b(buf, 1);
@@ -358,14 +366,14 @@ __global__ void __launch_bounds__(512, 1) topk_gscan_kernel(GscanArgs g) {
             }
             GS_BAR();
             GS_LGKM0();
-            mma(0, 1);
+            mma(0, 1, kt == 0);
             GS_BAR();
             // phase 3
             read_a(buf, 1);
             if (more && !k0_after) stage_Bb1(skt, nb);
             GS_BAR();
             GS_LGKM0();
-            mma(1, 1);
+            mma(1, 1, kt == 0);
             GS_BAR();
             // phase 4
             if (k0_after) {
@@ -375,7 +383,7 @@ __global__ void __launch_bounds__(512, 1) topk_gscan_kernel(GscanArgs g) {
                 wait_vmcnt<4>();
             }
             GS_BAR();
-            mma(1, 0);
+            mma(1, 0, kt == 0);
             GS_BAR();
         }
         prestaged = false;
@@ -394,7 +402,6 @@ __global__ void __launch_bounds__(512, 1) topk_gscan_kernel(GscanArgs g) {
         if (wr == 1) GS_BAR();
         if (!has_next) break;
         prestaged = true;
-        zero_acc();
         tile = next_tile;
         cur_row0 = nxt_row0;
         cur_q0 = nxt_q0;
@@ -471,11 +478,11 @@ int vm_topk_gscan(vm_memory *m, const void *queries, int Q, int q_thr, const flo
     }
     g.QX = (qx_env == 1 || qx_env == 2 || qx_env == 4 || qx_env == 8) ? qx_env : best_qx;
     auto kern = m->dtype == VM_F16 ? topk_gscan_kernel<VM_F16> : topk_gscan_kernel<VM_BF16>;
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[m->dtype == VM_F16 ? 0 : 1]) {
+    static unsigned long long attr_set[2] = {0, 0};   // per dtype, one bit per device
+    if (!((attr_set[m->dtype == VM_F16 ? 0 : 1] >> (m->ctx->device & 63)) & 1ull)) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GS_LDS);
         if (e != hipSuccess) return vm_fail(m->ctx, VM_ERR_HIP, "gscan LDS opt-in %d: %s", GS_LDS, hipGetErrorString(e));
-        attr_set[m->dtype == VM_F16 ? 0 : 1] = true;
+        attr_set[m->dtype == VM_F16 ? 0 : 1] |= 1ull << (m->ctx->device & 63);
     }
     vm_prof_scope prof(m->ctx, VM_PROF_TOPK_SCAN, st);
     kern<<<m->ctx->num_cus, 512, GS_LDS, st>>>(g);

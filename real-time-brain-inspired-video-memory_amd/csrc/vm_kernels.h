@@ -30,6 +30,7 @@ struct GemmArgs {
                              // (0 = 1): lets a GEMM over the CLS rows alone write into the all-rows q blocks
     int stream_out;     // set by vm_gemm: the 16-bit output is larger than L2 and leaves with the non-temporal policy
     int fgroup;         // set by vm_gemm: feature tiles per group of the persistent kernel's tile order (0 = all)
+    int explicit_zero;  // set by vm_gemm (developer A/B, VIDMEM_GEMM_ZERO=1): clear accumulators per tile instead of C = 0
 };
 
 int vm_gemm(vm_ctx *ctx, int dtype, const GemmArgs &g, int epi, hipStream_t st);

@@ -309,3 +309,37 @@ def test_bench_size_batches_take_the_big_kernels_and_agree(name, dtype, n):
     want = V.vit_forward_ref(spec, w, px, quant=dtype)
     bar = CONTRACT if dtype == "f16" else floor_bar_full_clip()
     assert rel(big[:3].float().cpu().numpy(), want) < bar
+
+
+def test_long_attention_variants_agree(tmp_path):
+    """The 577-token attention has three builds behind process-level switches (csrc/attention.hip): two query tiles per
+    walk with a lazily raised softmax reference (default), one tile per walk (VIDMEM_ATTN_PAIR=0), and the two-pass
+    softmax against the exact row maximum (VIDMEM_ATTN_ONLINE=0).  Same softmax in all three: the embeddings may
+    differ by the rounding of the 16-bit probabilities only.  The switches are read once per process, hence one child
+    process per variant."""
+    import subprocess
+    import sys
+    prog = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+import vidmem
+from vidmem import synthetic as syn
+from vidmem.encoder import FrameEncoder
+spec = dict(arch="t", image=336, patch=14, hidden=256, layers=2, heads=4, mlp=512, act="quick_gelu", ln_eps=1e-5,
+            pre_ln=True, patch_bias=False, proj_dim=0, mean=(0.5,) * 3, std=(0.5,) * 3)
+enc = FrameEncoder(spec, syn.encoder_weights(spec, seed=3, std=0.05), "f16")
+assert enc.tokens == 577
+px = syn.normal(77, "px", (3, 3, 336, 336))
+np.save(sys.argv[2], enc.encode_patches(enc.patches_from_pixels(torch.from_numpy(px))).float().cpu().numpy())
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for name, env in (("pair", {}), ("single", {"VIDMEM_ATTN_PAIR": "0"}), ("two_pass", {"VIDMEM_ATTN_ONLINE": "0"})):
+        path = str(tmp_path / f"{name}.npy")
+        subprocess.check_call([sys.executable, "-c", prog, root, path], env=dict(os.environ, **env))
+        outs[name] = np.load(path)
+    assert np.isfinite(outs["pair"]).all()
+    for name in ("single", "two_pass"):
+        d = rel(outs[name], outs["pair"])
+        print(f"{name} vs pair: {d:.2e}")
+        assert d < 3e-4, (name, d)
