@@ -342,4 +342,7 @@ np.save(sys.argv[2], enc.encode_patches(enc.patches_from_pixels(torch.from_numpy
     for name in ("single", "two_pass"):
         d = rel(outs[name], outs["pair"])
         print(f"{name} vs pair: {d:.2e}")
-        assert d < 3e-4, (name, d)
+        # one tile per walk is the same arithmetic (measured: bit-identical); the two-pass build exponentiates against a
+        # different reference, so every 16-bit probability rounds independently (fp16: 2^-11 = 4.9e-4 per value;
+        # measured 3.5e-4 on the embedding of this two-layer stack)
+        assert d < (1e-6 if name == "single" else 6e-4), (name, d)
