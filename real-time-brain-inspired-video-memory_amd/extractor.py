@@ -161,6 +161,38 @@ class FrameEmbeddingExtractor:
             self._stager = factory(cap, h, w, self.encoder.device.index or 0)
         return self._stager.stage(frames)
 
+    def _group_search(self, emb_all: torch.Tensor, counts: List[int]):
+        """Neighbours of every frame of a look-ahead group in ONE pass, equal to the chunk-by-chunk loop of
+        src/pipeline/vlm_extractor.py:44-74 (search chunk i against everything before it, then append it):
+          (1) top-k of all the group's frames over the memory as it stands before the group (one launch);
+          (2) the group's own earlier chunks: all-pairs exact reference cosines (``vm_cosine_exact``: the same fp64
+              arithmetic on the same 16-bit values the memory's re-scoring uses), masked to "chunks before mine", k best by
+              (score descending, row ascending) - a stable sort over append order, row id = the id the row is about to get;
+          (3) ``vm_topk_merge`` of the two lists (the kernel that merges per-shard lists: same order relation).
+        Only called when no stored row can be overwritten while the group is appended (see the caller)."""
+        from .memory import topk_merge
+        F, k = emb_all.shape[0], self.top_k
+        dev = emb_all.device
+        base = len(self.memory)                                   # id of the group's first row
+        if self.memory.searchable:
+            s_mem, r_mem = self.memory.topk(emb_all, k)
+        else:
+            s_mem = torch.zeros((F, k), dtype=torch.float64, device=dev)
+            r_mem = torch.full((F, k), -1, dtype=torch.int64, device=dev)
+        starts = torch.repeat_interleave(torch.tensor([sum(counts[:i]) for i in range(len(counts))], device=dev),
+                                         torch.tensor(counts, device=dev))
+        g = self.memory.cosine_exact(emb_all, emb_all)            # [F, F] fp64
+        g = g.masked_fill(torch.arange(F, device=dev)[None, :] >= starts[:, None], float("-inf"))
+        kk = min(k, F)
+        vals, idx = torch.sort(g, dim=1, descending=True, stable=True)
+        vals, idx = vals[:, :kk], idx[:, :kk]
+        valid = vals > float("-inf")
+        s_grp = torch.zeros((F, k), dtype=torch.float64, device=dev)
+        r_grp = torch.full((F, k), -1, dtype=torch.int64, device=dev)
+        s_grp[:, :kk] = torch.where(valid, vals, torch.zeros_like(vals))
+        r_grp[:, :kk] = torch.where(valid, idx + base, torch.full_like(idx, -1))
+        return topk_merge(self.memory.ctx, torch.stack([s_mem, s_grp]), torch.stack([r_mem, r_grp]))
+
     async def process_video(self, video_path: str, output_path: str) -> str:
         run_id = str(uuid.uuid4())
         logger.info(f"Starting frame-embedding extraction with run ID: {run_id}")
@@ -260,23 +292,44 @@ class FrameEmbeddingExtractor:
                     self._stager.done(ticket)
                 credits.release()
                 chunks, dev_s, dev_r, off = [], [], [], 0
+                total = sum(counts)
+                # One search for the whole group when that is provably the same thing: every chunk of the group still
+                # sees exactly "the memory before the group + the group's earlier chunks", i.e. no row of the memory is
+                # overwritten while the group is appended (not a ring, or a ring that does not wrap inside the group).
+                batched = (len(grp) > 1 and emb_all is not None and self.top_k > 0 and emb_all.is_cuda and
+                           (not self.memory.ring or len(self.memory) + total <= self.memory.capacity))
+                if batched:
+                    grp_s, grp_r = self._group_search(emb_all, counts)
                 for (chunk_idx, start, end, indices, time_str), nframes in zip(grp, counts):
                     c = {"chunk_idx": chunk_idx, "time": time_str, "nframes": nframes, "searched": False, "first": 0}
                     chunks.append(c)
                     if not nframes:
                         continue
                     emb = emb_all[off:off + nframes]
-                    off += nframes
-                    if self.memory.searchable and self.top_k > 0:
+                    if batched:
+                        if self.memory.searchable + off > 0:       # what `memory.searchable` will be when chunk i's turn comes
+                            dev_s.append(grp_s[off:off + nframes])
+                            dev_r.append(grp_r[off:off + nframes])
+                            c["searched"] = True
+                    elif self.memory.searchable and self.top_k > 0:
                         scores, rows = self.memory.topk(emb, self.top_k)
                         dev_s.append(scores)
                         dev_r.append(rows)
                         c["searched"] = True
+                    off += nframes
                     ids = [f"{run_id}_{chunk_idx}_{i}" for i in range(nframes)]  # pre_llm_injector.py:91 id scheme
                     created = time.strftime("%Y-%m-%dT%H:%M:%S+00:00", time.gmtime())   # Chunk.created_at of the export
-                    c["first"] = self.memory.append(emb, ids=ids, meta=[{"time": time_str, "content": None,
-                                                                         "batch_id": chunk_idx,
-                                                                         "created_at": created}] * nframes)
+                    c["ids"] = ids
+                    c["meta"] = [{"time": time_str, "content": None, "batch_id": chunk_idx, "created_at": created}] * nframes
+                    if not batched:
+                        c["first"] = self.memory.append(emb, ids=ids, meta=c["meta"])
+                if batched:      # one append for the group: rows, ids and meta in chunk order
+                    live = [c for c in chunks if c["nframes"]]
+                    first = self.memory.append(emb_all, ids=[i for c in live for i in c["ids"]],
+                                               meta=[m for c in live for m in c["meta"]])
+                    for c in live:
+                        c["first"] = first
+                        first += c["nframes"]
                 host_s = host_r = ev = None
                 if dev_s:
                     cat_s, cat_r = torch.cat(dev_s), torch.cat(dev_r)

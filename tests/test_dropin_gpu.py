@@ -82,11 +82,16 @@ def test_extractor_from_config_alone_and_neighbours_against_the_oracle(tmp_path,
     assert ex2.memory.id_of(7) == f"{run_id}_1_1"
 
 
-def test_look_ahead_groups_change_nothing_but_the_time(tmp_path, monkeypatch):
-    """``encoder.look_ahead_chunks: N`` encodes N chunks per encoder call; every chunk still gets its own top-k against
-    the memory as it stood after the chunk before it and its own append (src/pipeline/vlm_extractor.py:44-74 order).
-    Stored rows, row numbers and reported neighbours (ids AND fp64 scores) must equal the N = 1 run exactly, with a
-    ragged last group, a ragged last chunk and a ring memory that wraps during the run."""
+@pytest.mark.parametrize("memory_cfg", [{"capacity": 48, "ring": True}, {"capacity": 4096, "ring": False},
+                                        {"capacity": 80, "ring": True}],
+                         ids=["ring-wraps", "grows", "ring-wraps-late"])
+def test_look_ahead_groups_change_nothing_but_the_time(tmp_path, monkeypatch, memory_cfg):
+    """``encoder.look_ahead_chunks: N`` encodes N chunks per encoder call; every chunk still sees the memory as it
+    stood after the chunk before it (src/pipeline/vlm_extractor.py:44-74 order) - by its own top-k and append when a
+    ring wraps inside the group, by ONE search per group (memory before the group + the group's earlier chunks through
+    the exact all-pairs kernel, merged) when nothing can be overwritten meanwhile.  Stored rows, row numbers and
+    reported neighbours (ids AND fp64 scores) must equal the N = 1 run exactly, with a ragged last group, a ragged last
+    chunk, an empty memory at the start, and a ring that wraps from the first / from a later group on."""
     from vidmem import config as C, specs, synthetic as syn
     from vidmem.extractor import FrameEmbeddingExtractor
     monkeypatch.setitem(specs.SPECS, "vit_b16_2l", dict(specs.VIT_B16_224, layers=2))
@@ -100,7 +105,7 @@ def test_look_ahead_groups_change_nothing_but_the_time(tmp_path, monkeypatch):
         cfg = C.from_dict({
             "video": {"chunk_size_seconds": 1.0, "frames_per_chunk": 7},
             "encoder": {"arch": "vit_b16_2l", "dtype": "f16", "seed": 3, "top_k": 4, "look_ahead_chunks": n},
-            "memory": {"capacity": 48, "ring": True},
+            "memory": memory_cfg,
         })
         ex = FrameEmbeddingExtractor(cfg, encoder=enc)
         enc = ex.encoder
