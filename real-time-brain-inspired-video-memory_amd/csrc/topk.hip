@@ -772,8 +772,8 @@ int run_topk_kl(vm_memory *m, const ScanPlan &p, const void *queries, int Q, int
     // everything below it (list scan) or emits only what is at or above it (emit scan, topk_emit.hip).
     const bool emit = p.emit;
     if (emit) {
-        // Cut cascade (topk_emit.hip / topk_gscan.hip), INCREMENTAL: pass 0 keeps every score of the physically first
-        // s0 rows; pass p scans only the slots [limit[p-1], limit[p]) against the KL-th best of the rows before them
+        // Cut cascade (topk_emit.hip / topk_gscan.hip), INCREMENTAL: pass 0 keeps every score of the NEWEST ~4 k
+        // rows; pass p scans only the slots [limit[p-1], limit[p]) against the KL-th best of the rows seen so far
         // and appends to the KL survivors the compact kernel seeded the buffer with.  Each cut is the KL-th best of a
         // SUBSET of the rows, so the KL best of that subset plus everything at or above the cut among the other rows
         // contain the KL best overall; no row is scanned twice.  With the limits growing 8-fold a pass emits about
@@ -793,9 +793,11 @@ int run_topk_kl(vm_memory *m, const ScanPlan &p, const void *queries, int Q, int
         // cand_cnt and mk are neighbours: one memset clears both
         hipError_t e = hipMemsetAsync(cand_cnt, 0, 2 * vm_align_up((size_t)p.q_pad * 4, 256), st);
         if (e != hipSuccess) return vm_fail(m->ctx, VM_ERR_HIP, "memset: %s", hipGetErrorString(e));
-        int64_t begin = 0, limit = VM_EMIT_CAP;  // pass 0: slot = physical row index, dense
+        // pass 0: DENSE over the newest <= 4,095 rows (dense_newest: their physical range is computed on the device);
+        // passes 1.. : the physical slots [0, 32768), [32768, 262144), ... minus the dense rows
+        int64_t begin = 0, limit = 0;
         for (int pass = 0;; ++pass) {
-            const bool last = limit >= m->cap;
+            const bool last = pass > 0 && limit >= m->cap;
             if ((rc = vm_topk_emit_scan(m, queries, Q, p.q_pad, pass ? thr_s : nullptr, pass ? thr_o : nullptr, cand_cnt,
                                         cand_s, cand_o, begin, last ? INT64_MAX : limit, st)) != VM_OK)
                 return rc;
@@ -804,7 +806,7 @@ int run_topk_kl(vm_memory *m, const ScanPlan &p, const void *queries, int Q, int
                 return rc;
             if (last) break;
             begin = limit;
-            limit *= growth;
+            limit = pass == 0 ? (int64_t)VM_EMIT_CAP * growth : limit * growth;
         }
         mark = mk;
         fin_nblk = 1;

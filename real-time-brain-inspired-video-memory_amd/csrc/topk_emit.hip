@@ -139,6 +139,11 @@ __global__ void __launch_bounds__(EM_THREADS, 1)
     }
 
     RingView rv = ring_view(*d_total, cap, ring);
+    const DenseRange dense = dense_newest(rv);   // the rows of the dense pass (thr_s == null); skipped by the others
+    if (!thr_s) {
+        row_begin = dense.d0;
+        row_limit = dense.d1;
+    }
     if (rv.n > row_limit) rv.n = row_limit;  // cut cascade: a pass scans the physical slots [row_begin, row_limit) only
     const int64_t tile0 = row_begin / EM_ROWS;                                  // row_begin is a multiple of EM_ROWS
     const int64_t ntiles = rv.n > row_begin ? (rv.n + EM_ROWS - 1) / EM_ROWS - tile0 : 0;
@@ -344,9 +349,9 @@ __global__ void __launch_bounds__(EM_THREADS, 1)
                         const int64_t p = p0 + j;
                         int64_t o64 = p - rv.head;
                         if (o64 < 0) o64 += rv.cap;
-                        if (have && p < rv.n && p < VM_EMIT_CAP) {  // slot = physical row index: dense in [0, n)
-                            cand_s[(size_t)myq[u] * VM_EMIT_CAP + p] = sv[j];
-                            cand_o[(size_t)myq[u] * VM_EMIT_CAP + p] = (int)o64;
+                        if (have && p < rv.n && p - dense.d0 < VM_EMIT_CAP) {  // slot = index inside the dense range
+                            cand_s[(size_t)myq[u] * VM_EMIT_CAP + (p - dense.d0)] = sv[j];
+                            cand_o[(size_t)myq[u] * VM_EMIT_CAP + (p - dense.d0)] = (int)o64;
                         }
                     }
                     continue;
@@ -360,7 +365,8 @@ __global__ void __launch_bounds__(EM_THREADS, 1)
                     if (o64 < 0) o64 += rv.cap;
                     const int o = (int)o64;
                     const float sc = sv[j];
-                    const bool pass = p < rv.n && !better(ts[u], to[u], sc, o);  // at or above the cut
+                    const bool pass = p < rv.n && !(p >= dense.d0 && p < dense.d1) &&  // (dense rows are candidates already)
+                                      !better(ts[u], to[u], sc, o);                    // at or above the cut
                     const unsigned long long m = __ballot(pass);
                     if (m) {  // wave-uniform
                         if (pending > EM_WBUF - 64) flush();
@@ -387,7 +393,7 @@ __global__ void __launch_bounds__(EM_THREADS, 1)
 #pragma unroll
         for (int u = 0; u < NG; ++u)
             if (ts[u] != INFINITY && h == 0)
-                cand_cnt[myq[u]] = (int)(rv.n < VM_EMIT_CAP ? rv.n : VM_EMIT_CAP);
+                cand_cnt[myq[u]] = (int)(dense.d1 - dense.d0);   // <= 4,095 by construction
     }
 }
 
@@ -530,7 +536,7 @@ int launch_emit(vm_memory *m, const void *queries, int Q, const float *thr_s, co
     const int nsuper = (Q + EM_QPB * NG - 1) / (EM_QPB * NG);
     int nbx = m->ctx->num_cus / nsuper;
     if (nbx < 1) nbx = 1;
-    const int64_t rows = (m->cap < row_limit ? m->cap : row_limit) - row_begin;
+    const int64_t rows = thr_s ? (m->cap < row_limit ? m->cap : row_limit) - row_begin : (int64_t)VM_EMIT_CAP;
     const int64_t ntiles = rows > 0 ? (rows + EM_ROWS - 1) / EM_ROWS : 1;
     if (nbx > ntiles) nbx = (int)ntiles;
     static int nt_env = -1;
@@ -590,11 +596,12 @@ size_t vm_topk_emit_workspace_bytes(int q_pad) {
 }
 
 // Scans the physical slots [row_begin, min(n, row_limit)) and APPENDS the candidates (cand_cnt: zero, or the seed
-// count the previous pass's compact left).  thr_s == null (dense pass): row_begin = 0 and cand_cnt zero.
+// count the previous pass's compact left).  thr_s == null: the DENSE pass - every score of the newest rows
+// (dense_newest, vm_internal.h; computed on the device, row_begin / row_limit ignored), cand_cnt zero.
 // Very many queries over many rows take the GEMM-class scan (topk_gscan.hip).
 int vm_topk_emit_scan(vm_memory *m, const void *queries, int Q, int q_thr, const float *thr_s, const int *thr_o,
                       int *cand_cnt, float *cand_s, int *cand_o, int64_t row_begin, int64_t row_limit, hipStream_t st) {
-    if (row_begin % EM_ROWS != 0 || (!thr_s && row_begin != 0))
+    if (row_begin % EM_ROWS != 0)
         return vm_fail(m->ctx, VM_ERR_INVALID, "emit scan: row_begin %lld", (long long)row_begin);
     if (thr_s && row_begin % 256 == 0 &&
         vm_topk_gscan_supported(m, Q, (m->cap < row_limit ? m->cap : row_limit) - row_begin))

@@ -90,6 +90,7 @@ __global__ void __launch_bounds__(512, 1) topk_gscan_kernel(GscanArgs g) {
     int nq_x = nqt - qt0;
     if (nq_x > qpx) nq_x = qpx;
     const RingView rv = ring_view(*g.d_total, g.cap, g.ring);
+    const DenseRange dense = dense_newest(rv);   // already candidates (the cascade's dense pass): never emitted here
     const int64_t r_hi = rv.n < g.row_limit ? rv.n : g.row_limit;
     const int nrp = r_hi > g.row_begin ? (int)((r_hi - g.row_begin + 255) >> 8) : 0;
     const int np_x = nrp > rx ? (nrp - rx + RX - 1) / RX : 0;
@@ -251,7 +252,7 @@ __global__ void __launch_bounds__(512, 1) topk_gscan_kernel(GscanArgs g) {
             int64_t o64 = p - rv.head;
             if (o64 < 0) o64 += rv.cap;
             const int o = (int)o64;
-            bool pass = p < r_hi && sc >= cut;
+            bool pass = p < r_hi && !(p >= dense.d0 && p < dense.d1) && sc >= cut;
             if (__ballot(pass && sc == cut)) {  // a tie with the cut itself
                 const int to = qj < g.Q ? g.thr_o[qj] : -1;
                 if (sc == cut && o > to) pass = false;

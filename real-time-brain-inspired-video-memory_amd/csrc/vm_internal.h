@@ -35,6 +35,30 @@ __host__ __device__ inline RingView ring_view(int64_t total, int64_t cap, int ri
     return v;
 }
 
+// The rows whose every score the cut cascade keeps in its first, DENSE pass: the NEWEST stored rows (at most 4,095 of
+// them, a whole number of 256-row panels plus the ragged end).  New rows are what a video's current frames resemble
+// most - a scene lasts thousands of frames - so the first cut is high and the later passes emit little; with the
+// physically first rows as the dense set, a growing (non-ring) memory whose newest few thousand rows all beat the cut of
+// the old ones overflowed every query's candidate buffer in the last pass and sent the whole batch to the exhaustive
+// redo (correct, 1 s instead of 1 ms: found by the extractor bench leg on a clip processed twice).
+// Physical slots [d0, d1); the later passes scan [0, n) in physical order and skip these.
+struct DenseRange {
+    int64_t d0, d1;
+};
+__host__ __device__ inline DenseRange dense_newest(const RingView &rv) {
+    const int64_t end = rv.head ? rv.head : rv.n;   // physical end (exclusive) of the newest rows
+    const int64_t e_al = end & ~(int64_t)255;
+    DenseRange r;
+    if (e_al >= 3840) {
+        r.d0 = e_al - 3840;
+        r.d1 = end;
+    } else {   // fewer than 15 panels before the end: the physically first rows (they contain the newest ones)
+        r.d0 = 0;
+        r.d1 = rv.n < 4095 ? rv.n : 4095;
+    }
+    return r;
+}
+
 // ---- emit-only many-query scan (topk_emit.hip), driven by topk.hip ---------------------------------------------
 constexpr int VM_EMIT_CAP = 4096;  // candidate slots per query; more -> the query is marked for the exhaustive redo
 bool vm_topk_emit_supported(const vm_memory *m, int Q, int KL);

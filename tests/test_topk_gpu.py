@@ -552,3 +552,29 @@ def test_gemm_class_scan_two_k_tiles():
     want_r, want_s = cref.cosine_topk(_bits(q[picks]), _bits(m), k, dtype="f16")
     assert np.array_equal(r[picks].cpu().numpy(), want_r) and np.array_equal(s[picks].cpu().numpy(), want_s)
     assert mem.uncertified_count <= 2
+
+
+@pytest.mark.parametrize("Q", [64, 600])
+def test_newest_rows_form_the_dense_pass(Q):
+    """A growing (non-ring) memory whose NEWEST 6,000 rows all resemble the queries - a long scene at the end of a video -
+    behind 150,000 unrelated ones.  The cut cascade keeps every score of the newest ~4 k rows first, so its cut starts at
+    the scene's level; with the physically first rows as the dense set the last pass found 6,000 rows above the cut of
+    the old ones, every candidate buffer overflowed and the whole batch went to the exhaustive redo.  Answers equal the
+    exhaustive kernel's either way; what is pinned here is that (almost) nothing is redone.  Emit scan and GEMM-class
+    scan."""
+    rng = np.random.default_rng(6000 + Q)
+    D, M_old, M_new, k = 256, 150_000, 6_000, 10
+    old = torch.tensor(rng.standard_normal((M_old, D)), dtype=torch.float32)
+    centre = torch.tensor(rng.standard_normal((1, D)), dtype=torch.float32)
+    new = centre + 0.6 * torch.tensor(rng.standard_normal((M_new, D)), dtype=torch.float32)
+    q = (centre + 0.6 * torch.tensor(rng.standard_normal((Q, D)), dtype=torch.float32)).to(torch.float16)
+    mem = _mem("f16", M_old + M_new + 1000, D)
+    mem.append(old.to(torch.float16))
+    mem.append(new.to(torch.float16))
+    mem.reset_uncertified()
+    s, r = mem.topk(q, k)
+    redone = mem.uncertified_count
+    assert (r.cpu().numpy() >= M_old).all()                       # the neighbours are in the scene
+    s2, r2 = mem.topk(q, k, exact=True)
+    assert np.array_equal(r2.cpu().numpy(), r.cpu().numpy()) and np.array_equal(s2.cpu().numpy(), s.cpu().numpy())
+    assert redone <= Q // 50 + 1, redone
