@@ -3,7 +3,7 @@
 set -o pipefail
 R=$GRAFT_REPO_ROOT; T=${1:-r3p}; O=$R/gpurun_out/$T; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-A="--no-cpu-baseline --no-streaming --no-extractor --no-knn --steps 3 --warmup 1 --c3-frames 448 --no-two-stream"
+A="--no-cpu-baseline --no-streaming --no-extractor --steps 3 --warmup 1 --c3-frames 448 --no-two-stream"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py $A > $O/pmc_fetch.log 2>&1; echo "fetch rc=$?"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py $A > $O/pmc_write.log 2>&1; echo "write rc=$?"
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU --output-format csv -d $O/pmc_mfma -- python3 $R/bench.py $A > $O/pmc_mfma.log 2>&1; echo "mfma rc=$?"
