@@ -101,6 +101,17 @@ class HipPreLLMSimilarity:
             return [[] for _ in chunk_embeddings]
 
 
+def _zip_truncating_cosine(vec1, vec2) -> float:
+    """src/pipeline/retriever_hybrid.py:655-664, for operands of different lengths only (equal lengths go to the device)."""
+    import math
+    dot_product = sum(a * b for a, b in zip(vec1, vec2))
+    mag1 = math.sqrt(sum(a * a for a in vec1))
+    mag2 = math.sqrt(sum(b * b for b in vec2))
+    if mag1 * mag2 == 0:
+        return 0.0
+    return dot_product / (mag1 * mag2)
+
+
 class HipVectorSearch:
     """Mixin / stand-alone object for HybridRetriever's vector leg."""
 
@@ -164,13 +175,19 @@ class HipVectorSearch:
             # ONE [1, D] x [S, D] exact-cosine launch for all segments of all hits (the reference scores them one
             # by one in Python, :497); filter >= threshold in encounter order, then [:top_k] (:499-510).  The operands
             # are scored as fp32 values, not rounded to the memory's 16-bit type: they never enter the memory, and a
-            # threshold decision must not flip on a rounding the reference does not make.  A segment whose length differs
-            # from the query's is dropped (the reference's zip-truncating cosine, :655-664, has no defined meaning there).
-            keep = [i for i, e in zip(keep, seg_emb) if len(e) == len(query_embedding)]
-            seg_emb = [e for e in seg_emb if len(e) == len(query_embedding)]
-            if not seg_emb:
-                return []
-            sims = self.memory.cosine_exact([query_embedding], seg_emb, as_f32=True)[0].cpu().tolist()
+            # threshold decision must not flip on a rounding the reference does not make.  A segment whose embedding's
+            # length differs from the query's (an embedder that changed its model between calls) is scored on the host
+            # by the reference's own zip-truncating expression (:655-664: dot over the common prefix, each magnitude over
+            # its whole vector, ``mag1 * mag2 == 0`` -> 0.0) - three Python sums, as there.
+            same = [j for j, e in enumerate(seg_emb) if len(e) == len(query_embedding)]
+            sims = [0.0] * len(seg_emb)
+            if same:
+                dev = self.memory.cosine_exact([query_embedding], [seg_emb[j] for j in same], as_f32=True)[0].cpu().tolist()
+                for j, v in zip(same, dev):
+                    sims[j] = v
+            for j, e in enumerate(seg_emb):
+                if len(e) != len(query_embedding):
+                    sims[j] = _zip_truncating_cosine(query_embedding, e)
             kept = [{**owners[i], "content": segments[i], "compression_score": float(sim)}
                     for i, sim in zip(keep, sims) if sim >= self.config.compression_threshold]
             return kept[: self.config.top_k]

@@ -112,6 +112,11 @@ def test_post_compress_chunks_matches_reference_filter():
         chunks.append({"id": ids[c], "time": "t", "content": "|".join(parts), "score": 0.9 - 0.1 * c,
                        "source": "vector"})
     del segs["seg 1.1"]                                  # this segment's embed call fails: skipped, not fatal (:505-507)
+    # two segments come back with a DIFFERENT length than the query (the embedder changed its model): the reference's
+    # cosine zip-truncates (:655-664: dot over the common prefix, each magnitude over its own vector) - one of them ends
+    # up above the threshold, one below, and both must be treated exactly as the reference treats them
+    segs["seg 0.2"] = segs["seg 0.0"] + [0.001] * 7      # longer: same prefix as a kept segment, slightly larger norm
+    segs["seg 2.1"] = segs["seg 2.0"][: D // 2]          # shorter: half of a kept segment
     q16 = _f16_lists(q[None])[0]
     table = dict(segs, **{"the query": q16})
     cfg = SimpleNamespace(top_k_chunks=6, compression_threshold=0.6, top_k=4)
