@@ -392,7 +392,17 @@ __global__ void __launch_bounds__(FIN_THREADS)
     // KL.  One wave finds that cut with two bitwise binary searches held entirely in registers / SGPR ballots (the
     // KL-th largest score key, then among equal scores the needed count of smallest orders): ~1.3k instructions
     // instead of an O(lists^2) LDS rank count.
-    if (tid < 64) {
+    if (nblk == 1) {
+        // one list (the emit / GEMM-class scans hand over a single compacted list per query): it qualifies as it is - no
+        // head search (31 ballot rounds over MAX_BLOCKS list heads), no cut
+        if (tid == 0) {
+            const bool have = hs[0] > -INFINITY;
+            qual[0] = 0;
+            nqual = have ? 1 : 0;
+            cut_s_sh = -INFINITY;
+            cut_o_sh = INT_MAX;
+        }
+    } else if (tid < 64) {
         constexpr int HPL = MAX_BLOCKS / 64;
         unsigned key[HPL];
         int ord[HPL];

@@ -1,5 +1,6 @@
+"""Developer probe: the pieces of the extractor's one-search-per-group path (memory top-k, exact all-pairs, sort, mask)."""
 import sys, os, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, vidmem
 from vidmem.memory import EmbeddingMemory, topk_merge
 D, F, k = 768, 880, 10
