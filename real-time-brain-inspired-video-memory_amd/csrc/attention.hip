@@ -334,7 +334,6 @@ __device__ __forceinline__ void attend_pair_online(const char *kl, const char *v
     using E = vm_elem<DT>;
     using vec8 = typename E::vec8;
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    typedef short s8v __attribute__((__vector_size__(8 * sizeof(short))));
     constexpr int NS = (NT + 1) / 2;
     constexpr float ONLINE_SLACK = 6.0f;
     const int r16 = lane & 15, h = lane >> 4;
@@ -423,9 +422,11 @@ __device__ __forceinline__ void attend_pair_online(const char *kl, const char *v
                 n2[t] = f32x2{neg, neg};
             }
         }
-        vec8 pf[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        // Tile 0's probabilities first, then its four P.V MFMAs with tile 1's exponentials BETWEEN them (two 8-cycle
+        // transcendentals per 16-cycle MFMA), then tile 1's MFMAs.  With the MFMAs of both tiles paired per V fragment
+        // (the natural loop nest) every exponential of the step had to be finished before the second MFMA could issue:
+        // 16 v_exp + 8 converts with the matrix pipe idle, then 8 MFMAs with the vector pipe idle.
+        auto softmax_pack = [&](int t) -> vec8 {
             uint16_t pe[8];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -439,13 +440,25 @@ __device__ __forceinline__ void attend_pair_online(const char *kl, const char *v
                 pe[4 * u + 2] = E::from_float(p23.x);
                 pe[4 * u + 3] = E::from_float(p23.y);
             }
-            __builtin_memcpy(&pf[t], pe, 16);
-        }
+            vec8 pf;
+            __builtin_memcpy(&pf, pe, 16);
+            return pf;
+        };
+        vec8 av[4];
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            const s8v av = __builtin_shufflevector(vlo[dt], vhi[dt], 0, 1, 2, 3, 4, 5, 6, 7);
-            o[0][dt] = E::mfma16(__builtin_bit_cast(vec8, av), pf[0], o[0][dt]);
-            o[1][dt] = E::mfma16(__builtin_bit_cast(vec8, av), pf[1], o[1][dt]);
+        for (int dt = 0; dt < 4; ++dt)
+            av[dt] = __builtin_bit_cast(vec8, __builtin_shufflevector(vlo[dt], vhi[dt], 0, 1, 2, 3, 4, 5, 6, 7));
+        const vec8 pf0 = softmax_pack(0);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[0][dt] = E::mfma16(av[dt], pf0, o[0][dt]);
+        const vec8 pf1 = softmax_pack(1);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[1][dt] = E::mfma16(av[dt], pf1, o[1][dt]);
+        // schedule of the region above: (1 MFMA, 2 transcendentals) x 4 - tile 0's MFMAs over tile 1's exponentials
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
         }
     };
     constexpr int FULL_STEPS = EXACT ? (NT - 1) / 2 : 0;
