@@ -101,7 +101,10 @@ int vm_encoder_patch_k(const vm_encoder *enc);   /* 3*patch*patch rounded up to 
 int vm_encoder_out_dim(const vm_encoder *enc);   /* proj_dim ? proj_dim : hidden       */
 size_t vm_encode_workspace_bytes(const vm_encoder *enc, int B);
 /* Frames vm_encode runs per pass for a call with B frames (it walks B in micro-batches: a whole number of GEMM tile
- * rounds, and - for sequences that take one attention workgroup per (frame, head) - of attention rounds). */
+ * rounds, and - for sequences that take one attention workgroup per (frame, head) - of attention rounds).
+ * An encoder created with VIDMEM_ENC_DUAL=1 in the environment runs consecutive passes of a call on two internal
+ * streams (forked from / joined to the caller's stream inside vm_encode, still capturable); vm_encode_workspace_bytes
+ * then returns twice the single-pass size for calls of more than one pass.  Same embeddings either way. */
 int vm_encode_micro_batch(const vm_encoder *enc, int B);
 /* patches: [B, tokens-1, patch_k] dtype (vm_preprocess, PATCHES layout).  out_emb: [B, out_dim] dtype.
  * l2_normalise: divide each embedding by its L2 norm (fp32) before the cast. */
