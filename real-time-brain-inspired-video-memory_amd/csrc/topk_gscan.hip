@@ -1,4 +1,4 @@
-// Cosine top-k scan for VERY MANY queries per launch (Q >= ~512): the scan as a GEMM with an emit epilogue.
+// Cosine top-k scan for MANY queries per launch (Q >= 129 over a large memory): the scan as a GEMM with an emit epilogue.
 //
 // Same contract and call sites as topk.hip / topk_emit.hip (src/components/pre_llm_injector.py:346-388: every query
 // against every stored row; src/pipeline/retriever_hybrid.py:293-306).  This is the shape an 8-GPU step brings to every
@@ -420,7 +420,9 @@ bool vm_topk_gscan_supported(const vm_memory *m, int Q, int64_t rows) {
     static int min_q = -1;
     if (min_q < 0) {
         const char *e = getenv("VIDMEM_GSCAN_MINQ");
-        min_q = e ? atoi(e) : 512;
+        // from 129 queries on: up to 128 the emit scan's single superblock is HBM-bound and as fast; 160 / 384 queries
+        // over 1 M x 768 rows: 0.47 -> 0.44 ms / 0.92 -> 0.76 ms (the emit scan needs a second, half-empty superblock)
+        min_q = e ? atoi(e) : 129;
     }
     if (min_q <= 0 || Q < min_q || rows < 16384) return false;
     // enough 256 x 256 tiles for every CU to walk a few (a persistent tile walk with fewer leaves CUs idle for most of
