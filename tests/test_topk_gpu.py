@@ -530,25 +530,27 @@ def test_large_k_on_a_large_memory_stays_on_the_fast_path(k):
     mem.close()
 
 
-def test_gemm_class_scan_two_k_tiles():
+@pytest.mark.parametrize("M,Q", [(150_000, 520), (300_000, 160)], ids=["520q", "160q-one-ragged-tile"])
+def test_gemm_class_scan_two_k_tiles(M, Q):
     """D = 128: a score tile of the GEMM-class scan is two K-tiles deep, the shortest stream its tile-boundary logic
     (K-tile 0 staged during the previous tile's last K-tile, K-tile 1 at the boundary) can run on.  520 queries (three
-    query tiles, the last one 8 wide) over 150,000 rows, every query against the exhaustive kernel, 24 against the C oracle."""
+    query tiles, the last one 8 wide) over 150,000 rows / 160 queries (ONE ragged query tile: the smallest query count
+    the scan takes) over 300,000 rows; every query against the exhaustive kernel, two dozen against the C oracle."""
     rng = np.random.default_rng(128)
-    D, M, Q, k = 128, 150_000, 520, 10
+    D, k = 128, 10
     m = torch.tensor(rng.standard_normal((M, D)), dtype=torch.float32).to(torch.float16)
     q = torch.tensor(rng.standard_normal((Q, D)), dtype=torch.float32).to(torch.float16)
     q[:30] = (0.6 * m[rng.integers(0, M, 30)].float() + 0.4 * q[:30].float()).to(torch.float16)
     m[140_000] = m[77]
-    q[519] = m[77]
+    q[Q - 1] = m[77]
     mem = _mem("f16", M, D)
     mem.append(m)
     mem.reset_uncertified()
     s, r = mem.topk(q, k)
-    assert r[519, :2].tolist() == [77, 140_000]
+    assert r[Q - 1, :2].tolist() == [77, 140_000]
     s2, r2 = mem.topk(q, k, exact=True)
     assert np.array_equal(r2.cpu().numpy(), r.cpu().numpy()) and np.array_equal(s2.cpu().numpy(), s.cpu().numpy())
-    picks = np.unique(np.concatenate([np.arange(0, Q, 23), [511, 512, 519]]))
+    picks = np.unique(np.concatenate([np.arange(0, Q, 23), [Q - 9, Q - 8, Q - 1]]))
     want_r, want_s = cref.cosine_topk(_bits(q[picks]), _bits(m), k, dtype="f16")
     assert np.array_equal(r[picks].cpu().numpy(), want_r) and np.array_equal(s[picks].cpu().numpy(), want_s)
     assert mem.uncertified_count <= 2
