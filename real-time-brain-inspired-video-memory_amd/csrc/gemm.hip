@@ -19,6 +19,12 @@
 #include "vm_internal.h"
 #include "vm_kernels.h"
 #include "gemm_guard.h"
+#ifndef VM_GEMM_W_AUX
+#define VM_GEMM_W_AUX 0
+#endif
+#ifndef VM_GEMM_X_AUX
+#define VM_GEMM_X_AUX 0
+#endif
 
 namespace {
 
@@ -514,17 +520,21 @@ __global__ void __launch_bounds__(512, 1) gemm256p_kernel(GemmArgs g) {
         rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)(g.X + (size_t)t0s * g.ldx), 0,
                                                  (int)(((size_t)(vt - 1) * g.ldx + K) * 2), 0x00020000);
     };
-    auto dma2 = [&](const __amdgpu_buffer_rsrc_t rs, const unsigned (&voff)[2], unsigned vextra, unsigned soff,
-                    const int (&dst)[2], int extra, int buf) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(smem + buf * 4 * HALF_BYTES + dst[u] + extra), 16,
-                                                     voff[u] + vextra, soff, 0, 0);
-    };
-    auto stage_Wa0 = [&](int kt, int buf) { dma2(rs_w, voff_w, 0u, kt * (BK * 2), lds_wa0, 0, buf); };
-    auto stage_Wa1 = [&](int kt, int buf) { dma2(rs_w, voff_w, w64, kt * (BK * 2), lds_wa0, 64 * 128, buf); };
-    auto stage_Xb0 = [&](int kt, int buf) { dma2(rs_x, voff_x, 0u, kt * (BK * 2), lds_xb0, 0, buf); };
-    auto stage_Xb1 = [&](int kt, int buf) { dma2(rs_x, voff_x, x32, kt * (BK * 2), lds_xb0, 32 * 128, buf); };
+    // cache policy of the operand loads (aux bits of the buffer load: 2 = nt) is a build-time switch for the probe
+#define VM_DMA2(NAME, AUX)                                                                                            \
+    auto NAME = [&](const __amdgpu_buffer_rsrc_t rs, const unsigned (&voff)[2], unsigned vextra, unsigned soff,       \
+                    const int (&dst)[2], int extra, int buf) {                                                        \
+        _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                                 \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(smem + buf * 4 * HALF_BYTES + dst[u] + extra),   \
+                                                     16, voff[u] + vextra, soff, 0, AUX);                             \
+    }
+    VM_DMA2(dma2w, VM_GEMM_W_AUX);
+    VM_DMA2(dma2x, VM_GEMM_X_AUX);
+#undef VM_DMA2
+    auto stage_Wa0 = [&](int kt, int buf) { dma2w(rs_w, voff_w, 0u, kt * (BK * 2), lds_wa0, 0, buf); };
+    auto stage_Wa1 = [&](int kt, int buf) { dma2w(rs_w, voff_w, w64, kt * (BK * 2), lds_wa0, 64 * 128, buf); };
+    auto stage_Xb0 = [&](int kt, int buf) { dma2x(rs_x, voff_x, 0u, kt * (BK * 2), lds_xb0, 0, buf); };
+    auto stage_Xb1 = [&](int kt, int buf) { dma2x(rs_x, voff_x, x32, kt * (BK * 2), lds_xb0, 32 * 128, buf); };
 
     const int sw0 = ((h ^ (r16 & 7)) << 4), sw1 = (((h + 4) ^ (r16 & 7)) << 4);
     const int a_base = (wr * 128 + r16) * 128;
