@@ -5,7 +5,7 @@
 //   v_mfma_f32_16x16x32_f16: 16 KFLOP, A 4 + B 4 operand registers, 4 accumulators read and written
 //   v_mfma_f32_32x32x16_f16: 32 KFLOP, A 4 + B 4 operand registers, 16 accumulators read and written
 // build: hipcc --offload-arch=gfx950 -O3 tools/mfma_power_probe.hip -o tools/bin/mfma_power_probe
-// run:   tools/bin/mfma_power_probe [seconds per leg]     (ZERO=1: all-zero operands)
+// run:   tools/bin/mfma_power_probe [seconds per leg]     (ZERO=1: all-zero operands; LDS=1: legs with fragment reads)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -64,6 +64,39 @@ __global__ __launch_bounds__(512, 1) void loop32(const vec8 *src, float *sink, i
     if (s == 123.456f) sink[0] = s;
 }
 
+// loop16 plus the fragment reads of the GEMM: NR of the 12 fragments of a k-step (8 A + 4 B) come from LDS as
+// ds_read_b128 (conflict-free rows of 1 KiB, a different 12 KiB image every iteration), the others stay in registers.
+// NR = 12: the 128 x 64 wave tile of gemm256p (24 reads per 64 MFMAs); NR = 8: what a 128 x 128 wave tile would read
+// per FLOP (16 reads per 64 MFMAs); NR = 0: loop16.
+template <int NR>
+__global__ __launch_bounds__(512, 1) void loop16_lds(const vec8 *src, float *sink, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    for (int i = threadIdx.x; i < 96 * 1024 / 16; i += 512) reinterpret_cast<vec8 *>(smem)[i] = src[i % 4096];
+    __syncthreads();
+    vec8 f[12];
+    for (int i = 0; i < 12; ++i) f[i] = src[(i * 64 + (threadIdx.x & 63)) % 4096];
+    f32x4 acc[8][4] = {};
+    const int lane16 = (threadIdx.x & 63) * 16;
+    for (int it = 0; it < iters; ++it) {
+        const char *img = smem + (it & 7) * 12 * 1024 + lane16;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) f[i] = *reinterpret_cast<const vec8 *>(img + i * 1024);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[i], f[8 + j], acc[i][j], 0, 0, 0);
+        if (NR < 12) {   // rotate what is not reloaded so that every MFMA still sees changing operands
+            vec8 t = f[NR];
+#pragma unroll
+            for (int i = NR; i < 11; ++i) f[i] = f[i + 1];
+            f[11] = t;
+        }
+    }
+    float s = 0.f;
+    for (int i = 0; i < 8; ++i) for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (s == 123.456f) sink[0] = s;
+}
+
 int main(int argc, char **argv) {
     const double secs = argc > 1 ? atof(argv[1]) : 2.0;
     const bool zero = getenv("ZERO") != nullptr;
@@ -78,18 +111,28 @@ int main(int argc, char **argv) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int iters = 20000;                                   // 20000 x 32 x 16 KFLOP x 8 waves = 84 GFLOP per workgroup
     const double flop = (double)cus * 8 * iters * 32 * 2.0 * 16 * 16 * 32;
+    CK(hipFuncSetAttribute((const void *)loop16_lds<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    CK(hipFuncSetAttribute((const void *)loop16_lds<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    CK(hipFuncSetAttribute((const void *)loop16_lds<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    const bool lds = getenv("LDS") != nullptr;   // LDS=1: the fragment-read legs instead of the shape legs
+    const char *names[5] = {"16x16x32", "32x32x16", "16x16x32 + 12 ds_read_b128 / 32 MFMA", "16x16x32 + 8 ds_read_b128 / 32 MFMA",
+                            "16x16x32 + 4 ds_read_b128 / 32 MFMA"};
     for (int round = 0; round < 3; ++round)
-        for (int which = 0; which < 2; ++which) {
+        for (int which = lds ? 2 : 0; which < (lds ? 5 : 2); ++which) {
             double spent = 0, best = 1e9, sum = 0; int n = 0;
             while (spent < secs) {
                 CK(hipEventRecord(e0, 0));
-                if (which == 0) loop16<<<cus, 512>>>(src, sink, iters); else loop32<<<cus, 512>>>(src, sink, iters);
+                if (which == 0) loop16<<<cus, 512>>>(src, sink, iters);
+                else if (which == 1) loop32<<<cus, 512>>>(src, sink, iters);
+                else if (which == 2) loop16_lds<12><<<cus, 512, 96 * 1024>>>(src, sink, iters);
+                else if (which == 3) loop16_lds<8><<<cus, 512, 96 * 1024>>>(src, sink, iters);
+                else loop16_lds<4><<<cus, 512, 96 * 1024>>>(src, sink, iters);
                 CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
                 float ms; CK(hipEventElapsedTime(&ms, e0, e1));
                 spent += ms * 1e-3; sum += ms; ++n; if (ms < best) best = ms;
             }
             printf("round %d %s%s: %d launches, mean %.2f ms = %.0f TFLOP/s (best %.2f ms = %.0f)\n", round,
-                   which ? "32x32x16" : "16x16x32", zero ? " ZERO" : "", n, sum / n, flop / (sum / n * 1e-3) / 1e12, best,
+                   names[which], zero ? " ZERO" : "", n, sum / n, flop / (sum / n * 1e-3) / 1e12, best,
                    flop / (best * 1e-3) / 1e12);
             fflush(stdout);
         }
