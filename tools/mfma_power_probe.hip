@@ -68,8 +68,10 @@ __global__ __launch_bounds__(512, 1) void loop32(const vec8 *src, float *sink, i
 // ds_read_b128 (conflict-free rows of 1 KiB, a different 12 KiB image every iteration), the others stay in registers.
 // NR = 12: the 128 x 64 wave tile of gemm256p (24 reads per 64 MFMAs); NR = 8: what a 128 x 128 wave tile would read
 // per FLOP (16 reads per 64 MFMAs); NR = 0: loop16.
-template <int NR>
-__global__ __launch_bounds__(512, 1) void loop16_lds(const vec8 *src, float *sink, int iters) {
+// DMA = 1 adds the GEMM's staging: 4 LDS-DMA instructions of 1 KiB per wave and 32 MFMAs (64 KiB per workgroup and
+// 64-deep K-tile) out of a 2 MiB buffer that stays in every L2, retired with a counted wait.
+template <int NR, int DMA>
+__global__ __launch_bounds__(512, 1) void loop16_lds(const vec8 *src, float *sink, int iters, const char *pool) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     for (int i = threadIdx.x; i < 96 * 1024 / 16; i += 512) reinterpret_cast<vec8 *>(smem)[i] = src[i % 4096];
     __syncthreads();
@@ -79,6 +81,15 @@ __global__ __launch_bounds__(512, 1) void loop16_lds(const vec8 *src, float *sin
     const int lane16 = (threadIdx.x & 63) * 16;
     for (int it = 0; it < iters; ++it) {
         const char *img = smem + (it & 7) * 12 * 1024 + lane16;
+        if (DMA) {
+            const int wave = threadIdx.x >> 6;
+            const unsigned off = ((unsigned)(it * 4) * 8192u + wave * 1024u + blockIdx.x * 64u * 1024u) & (2u * 1024 * 1024 - 1);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pool + ((off + u * 8192u) & (2u * 1024 * 1024 - 1)) + lane16),
+                                                 (__attribute__((address_space(3))) void *)(smem + 96 * 1024 + wave * 4096 + u * 1024), 16, 0, 0);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        }
 #pragma unroll
         for (int i = 0; i < NR; ++i) f[i] = *reinterpret_cast<const vec8 *>(img + i * 1024);
 #pragma unroll
@@ -108,15 +119,18 @@ int main(int argc, char **argv) {
     vec8 *src; float *sink;
     CK(hipMalloc(&src, h.size() * 2)); CK(hipMalloc(&sink, 4));
     CK(hipMemcpy(src, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+    char *pool; CK(hipMalloc(&pool, 2u * 1024 * 1024 + 4096));
+    { std::vector<_Float16> hp(1024 * 1024 + 2048); for (auto &v : hp) v = zero ? (_Float16)0.f : (_Float16)((rand() / (float)RAND_MAX * 2.f - 1.f) * 0.25f);
+      CK(hipMemcpy(pool, hp.data(), hp.size() * 2, hipMemcpyHostToDevice)); }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int iters = 20000;                                   // 20000 x 32 x 16 KFLOP x 8 waves = 84 GFLOP per workgroup
     const double flop = (double)cus * 8 * iters * 32 * 2.0 * 16 * 16 * 32;
-    CK(hipFuncSetAttribute((const void *)loop16_lds<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    CK(hipFuncSetAttribute((const void *)loop16_lds<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    CK(hipFuncSetAttribute((const void *)loop16_lds<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    CK(hipFuncSetAttribute((const void *)loop16_lds<12, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    CK(hipFuncSetAttribute((const void *)loop16_lds<8, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    CK(hipFuncSetAttribute((const void *)loop16_lds<12, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     const bool lds = getenv("LDS") != nullptr;   // LDS=1: the fragment-read legs instead of the shape legs
     const char *names[5] = {"16x16x32", "32x32x16", "16x16x32 + 12 ds_read_b128 / 32 MFMA", "16x16x32 + 8 ds_read_b128 / 32 MFMA",
-                            "16x16x32 + 4 ds_read_b128 / 32 MFMA"};
+                            "16x16x32 + 12 ds_read_b128 + 4 KiB LDS-DMA from L2 / 32 MFMA"};
     for (int round = 0; round < 3; ++round)
         for (int which = lds ? 2 : 0; which < (lds ? 5 : 2); ++which) {
             double spent = 0, best = 1e9, sum = 0; int n = 0;
@@ -124,9 +138,9 @@ int main(int argc, char **argv) {
                 CK(hipEventRecord(e0, 0));
                 if (which == 0) loop16<<<cus, 512>>>(src, sink, iters);
                 else if (which == 1) loop32<<<cus, 512>>>(src, sink, iters);
-                else if (which == 2) loop16_lds<12><<<cus, 512, 96 * 1024>>>(src, sink, iters);
-                else if (which == 3) loop16_lds<8><<<cus, 512, 96 * 1024>>>(src, sink, iters);
-                else loop16_lds<4><<<cus, 512, 96 * 1024>>>(src, sink, iters);
+                else if (which == 2) loop16_lds<12, 0><<<cus, 512, 128 * 1024>>>(src, sink, iters, pool);
+                else if (which == 3) loop16_lds<8, 0><<<cus, 512, 128 * 1024>>>(src, sink, iters, pool);
+                else loop16_lds<12, 1><<<cus, 512, 128 * 1024>>>(src, sink, iters, pool);
                 CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
                 float ms; CK(hipEventElapsedTime(&ms, e0, e1));
                 spent += ms * 1e-3; sum += ms; ++n; if (ms < best) best = ms;
