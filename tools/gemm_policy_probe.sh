@@ -1,6 +1,12 @@
 # Cache-policy probe of the persistent GEMM's operand loads (run through gpurun): harness binaries built with
 # -DVM_GEMM_X_AUX / -DVM_GEMM_W_AUX (tools/bin/gemm_bench_{a: default, b: X nt, c: W nt, d: both}), FC1 at the bench
 # micro-batch (173,360 rows), time without the profiler and FETCH_SIZE / WRITE_SIZE with it.
+# Build (in the container, from the repo root; P = the package directory):
+#   hipcc --offload-arch=gfx950 -O3 -std=c++17 -c tools/gemm_bench.hip -o /tmp/gemm_bench.o
+#   for v in "0 0 a" "2 0 b" "0 2 c" "2 2 d"; do set -- $v
+#     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DVM_GEMM_ABLATE -DVM_GEMM_X_AUX=$1 \
+#           -DVM_GEMM_W_AUX=$2 -Iinclude -c $P/csrc/gemm.hip -o /tmp/gemm_abl_$3.o
+#     hipcc --offload-arch=gfx950 /tmp/gemm_bench.o /tmp/gemm_abl_$3.o $P/csrc/context.o -o tools/bin/gemm_bench_$3; done
 set -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-pol}; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
