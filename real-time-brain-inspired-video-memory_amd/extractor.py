@@ -51,6 +51,13 @@ class _ArraySource:
     def read(self, idx: int) -> Optional[np.ndarray]:
         return self.frames[idx] if 0 <= idx < self.total else None
 
+    def read_many(self, picks: List[int]) -> np.ndarray:
+        """The frames at ``picks`` (all readable) as ONE [n,H,W,3] array: a view of the clip when the picks are
+        consecutive (every frame of consecutive chunks: the staging copy is then one slab), a gathered copy otherwise."""
+        if picks and picks[-1] - picks[0] == len(picks) - 1 and all(b - a == 1 for a, b in zip(picks, picks[1:])):
+            return self.frames[picks[0]:picks[-1] + 1]
+        return self.frames[np.asarray(picks, dtype=np.int64)]
+
     def release(self):
         pass
 
@@ -179,10 +186,17 @@ class FrameEmbeddingExtractor:
         else:
             s_mem = torch.zeros((F, k), dtype=torch.float64, device=dev)
             r_mem = torch.full((F, k), -1, dtype=torch.int64, device=dev)
-        starts = torch.repeat_interleave(torch.tensor([sum(counts[:i]) for i in range(len(counts))], device=dev),
-                                         torch.tensor(counts, device=dev))
+        col = torch.arange(F, device=dev)
+        if all(c == counts[0] for c in counts):
+            # equal chunks (every group but a clip's ragged last one): the first row of each frame's chunk is computed
+            # on the device.  A host list would have to be COPIED in stream order, i.e. the host would sit behind the
+            # encoder launches it has just queued, and the GPU would idle afterwards while the host catches up
+            starts = col // counts[0] * counts[0]
+        else:
+            starts = torch.repeat_interleave(torch.tensor([sum(counts[:i]) for i in range(len(counts))], device=dev),
+                                             torch.tensor(counts, device=dev))
         g = self.memory.cosine_exact(emb_all, emb_all)            # [F, F] fp64
-        g = g.masked_fill(torch.arange(F, device=dev)[None, :] >= starts[:, None], float("-inf"))
+        g = g.masked_fill(col[None, :] >= starts[:, None], float("-inf"))
         kk = min(k, F)
         vals, idx = torch.sort(g, dim=1, descending=True, stable=True)
         vals, idx = vals[:, :kk], idx[:, :kk]
@@ -225,6 +239,14 @@ class FrameEmbeddingExtractor:
                 if gi >= len(groups):
                     return None
                 counts, frames = [], []
+                read_many = getattr(src, "read_many", None)
+                if read_many is not None:     # array sources: the group's picks in one gather (no per-frame Python)
+                    picks: List[int] = []
+                    for (_ci, _s, _e, indices, _t) in groups[gi]:
+                        ok = [i for i in indices if 0 <= i < src.total]      # an unreadable frame is dropped (:111)
+                        counts.append(len(ok))
+                        picks += ok
+                    return counts, (self._stage(read_many(picks), L) if picks else None)
                 for (_ci, _s, _e, indices, _t) in groups[gi]:
                     fr = self._read_chunk(src, indices)
                     counts.append(len(fr))

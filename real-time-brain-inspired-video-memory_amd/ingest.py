@@ -46,6 +46,9 @@ class FrameStager:
         self.consumed: List[Optional[torch.cuda.Event]] = [None] * self.depth
         self._seq = 0
         self.bytes_staged = 0
+        import os
+        self.copy_threads = max(1, min(4, (os.cpu_count() or 2) // 2))   # slab copies of array sources (``stage``)
+        self._pool = None
 
     def next_slot(self) -> np.ndarray:
         """Writable pinned host view [frames_per_chunk,H,W,3] of the slot the next ``commit`` will send: a decoder can
@@ -74,11 +77,31 @@ class FrameStager:
 
     def stage(self, frames: Union[np.ndarray, Sequence[np.ndarray]]) -> Ticket:
         """Pack ``frames`` (uint8 BGR [n,H,W,3] or a list of [H,W,3], n <= frames_per_chunk) into the next slot and
-        start its H2D copy.  Returns immediately after the host-side memcpy."""
+        start its H2D copy.  Returns immediately after the host-side memcpy.  An [n,H,W,3] ARRAY (a slab of a memory-
+        mapped clip, extractor._ArraySource.read_many) is copied in a few slices on worker threads: one thread moves
+        ~4-5 GB/s out of a page-cache mapping, which is less than the encoder consumes (25 k 224x224 frames/s = 3.8 GB/s
+        leaves no margin for the rest of the host loop)."""
         n = len(frames)
         if n == 0 or n > self.shape[0]:
             raise ValueError(f"a chunk holds 1..{self.shape[0]} frames, got {n}")
         hv = self.next_slot()
+        if isinstance(frames, np.ndarray):
+            if frames.shape[1:] != self.shape[1:] or frames.dtype != np.uint8:
+                raise ValueError(f"frames: expected uint8 [n, {self.shape[1:]}], got {frames.dtype} {frames.shape}")
+            parts = min(self.copy_threads, max(1, n * frames[0].nbytes // (8 << 20)))
+            if parts <= 1:
+                hv[:n] = frames
+            else:
+                if self._pool is None:
+                    from concurrent.futures import ThreadPoolExecutor
+                    self._pool = ThreadPoolExecutor(max_workers=self.copy_threads, thread_name_prefix="vidmem-copy")
+                cuts = [n * i // parts for i in range(parts + 1)]
+
+                def copy(a, b):
+                    hv[a:b] = frames[a:b]          # numpy releases the GIL for the copy
+                for fut in [self._pool.submit(copy, cuts[i], cuts[i + 1]) for i in range(parts)]:
+                    fut.result()
+            return self.commit(n)
         for i in range(n):
             f = frames[i]
             if f.shape != self.shape[1:] or f.dtype != np.uint8:
