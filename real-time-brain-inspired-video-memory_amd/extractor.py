@@ -217,6 +217,7 @@ class FrameEmbeddingExtractor:
             total_chunks, plan = chunk_plan(fps, total_frames, video_cfg.chunk_size_seconds,
                                             video_cfg.frames_per_chunk)
             results = []
+            result_lines: List[str] = []      # results[i] as JSON text (finish)
             # Look-ahead groups (config.encoder.look_ahead_chunks, default 1 = the reference's one chunk at a time,
             # :44-74): the frames of N consecutive chunks go through ONE encoder call - the encoder fills the chip only
             # from a few hundred frames up - and then every chunk of the group, in chunk order, gets its own top-k
@@ -277,6 +278,8 @@ class FrameEmbeddingExtractor:
                         "embedding_rows": list(range(c["first"], c["first"] + c["nframes"])),
                         "similar": similar,
                     })
+                    # serialised here, while the GPU works on the next group, not in one piece after the last one
+                    result_lines.append(json.dumps(results[-1], default=str))
                     self.timings.append((f"chunk_{c['chunk_idx']}", chunk_time))
                     self.metrics.record_timing(f"chunk_{c['chunk_idx']}", "vlm_inference", chunk_time)   # key of :73
 
@@ -378,7 +381,7 @@ class FrameEmbeddingExtractor:
                 f.write('{\n  "metadata": ')
                 f.write(json.dumps(output_data["metadata"], indent=2, default=str).replace("\n", "\n  "))
                 f.write(',\n  "results": [')
-                f.write(",".join("\n    " + json.dumps(r, default=str) for r in results))
+                f.write(",".join("\n    " + line for line in result_lines))
                 f.write("\n  ]\n}\n" if results else "]\n}\n")
             logger.info(f"Frame-embedding extraction completed. Output saved to: {output_path}")
             import os
