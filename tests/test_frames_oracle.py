@@ -155,3 +155,25 @@ def test_cv2_source_branch_with_a_stand_in_module(tmp_path, monkeypatch):
     assert len(got) == 2 and np.array_equal(got[1], frames[6])             # the unreadable pick is dropped
     src.release()
     assert log == [("open", str(tmp_path / "clip.mp4")), ("release",)]
+
+
+def test_array_source_group_reads(tmp_path):
+    """``_ArraySource.read_many`` (the slab path of the extractor's staging thread): a view of the clip for consecutive
+    picks, a gathered copy for the reference's ``np.linspace`` picks with gaps (src/pipeline/vlm_extractor.py:107);
+    either way the frames ``read`` returns one by one."""
+    from vidmem import extractor as X
+    frames = np.random.default_rng(6).integers(0, 256, size=(40, 6, 5, 3), dtype=np.uint8)
+    p = tmp_path / "clip.npy"
+    np.save(p, frames)
+    src = X.open_source(str(p))
+    assert src.total == 40 and src.fps == 30.0
+    run = src.read_many(list(range(7, 23)))
+    assert run.shape == (16, 6, 5, 3) and np.shares_memory(run, src.frames) and (run == frames[7:23]).all()
+    picks = [int(i) for i in np.linspace(3, 38, 8, dtype=int)]
+    got = src.read_many(picks)
+    assert (got == np.stack([src.read(i) for i in picks])).all() and not np.shares_memory(got, src.frames)
+    assert src.read(40) is None and src.read(-1) is None
+    # the plan's picks of a whole group, chunk after chunk, are one run when every frame of a chunk is picked
+    _n, plan = X.chunk_plan(30.0, 40, 16 / 30 + 1e-9, 16)
+    allp = [i for (_c, _s, _e, idx, _t) in plan for i in idx]
+    assert allp == list(range(32)) and np.shares_memory(src.read_many(allp), src.frames)
