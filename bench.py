@@ -22,6 +22,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL between the ranks' processes); exported on the boxes already
 os.environ.setdefault("VIDGRAPH_LOG_LEVEL", "WARNING")   # the drop-in classes log to stdout like the reference's; this
                                                           # program's stdout carries exactly one JSON line
 
