@@ -27,7 +27,8 @@ ENCODER_DEFAULTS: Dict[str, Any] = {
     "seed": 42,              # seed of the synthetic weights (no checkpoint can be fetched offline)
     "device": 0,
     "top_k": 5,              # neighbours reported per frame in the output JSON (`similar`)
-    "look_ahead_chunks": 1,  # chunks encoded per encoder call (extractor.py: same neighbours and rows as 1, bit for bit)
+    "look_ahead_chunks": 1,  # chunks encoded per encoder call (extractor.py: same neighbours and rows as 1, bit for bit);
+                             # 0 = as many as fill one encoder pass within a staging budget (offline files)
 }
 MEMORY_DEFAULTS: Dict[str, Any] = {
     "capacity": 100_000,     # rows resident in HBM (the reference caps its read-back at 5000: pre_llm_injector.py:398)

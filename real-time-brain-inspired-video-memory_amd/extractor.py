@@ -47,6 +47,7 @@ logger = get_logger("vidmem.extractor")
 class _ArraySource:
     def __init__(self, frames: np.ndarray, fps: float):
         self.frames, self.fps, self.total = frames, float(fps), int(frames.shape[0])
+        self.frame_hw = (int(frames.shape[1]), int(frames.shape[2]))
 
     def read(self, idx: int) -> Optional[np.ndarray]:
         return self.frames[idx] if 0 <= idx < self.total else None
@@ -69,6 +70,8 @@ class _Cv2Source:
         self.cap = cv2.VideoCapture(path)
         self.fps = self.cap.get(cv2.CAP_PROP_FPS)
         self.total = int(self.cap.get(cv2.CAP_PROP_FRAME_COUNT))
+        h, w = self.cap.get(cv2.CAP_PROP_FRAME_HEIGHT), self.cap.get(cv2.CAP_PROP_FRAME_WIDTH)
+        self.frame_hw = (int(h), int(w)) if h and w else None
 
     def read(self, idx: int) -> Optional[np.ndarray]:
         self.cap.set(self.cv2.CAP_PROP_POS_FRAMES, idx)
@@ -168,6 +171,19 @@ class FrameEmbeddingExtractor:
             self._stager = factory(cap, h, w, self.encoder.device.index or 0)
         return self._stager.stage(frames)
 
+    def _auto_look_ahead(self, src, frames_per_chunk: int, slot_bytes: int = 256 << 20) -> int:
+        """``look_ahead_chunks: 0``: as many chunks per group as fill one encoder pass (FrameEncoder.micro_batch: 883
+        frames of ViT-B/16, 224 of CLIP-L/14-336), as long as one staging slot of the group's source frames stays under
+        ``slot_bytes`` of pinned host memory (two such slots exist, and two on the device: 1080p frames are 6.2 MB each).
+        A source that does not say its frame size, or an encoder stand-in without ``micro_batch``, gets 1."""
+        hw = getattr(src, "frame_hw", None)
+        mb = getattr(self.encoder, "micro_batch", None)
+        if hw is None or mb is None or frames_per_chunk <= 0:
+            return 1
+        by_pass = int(mb(10 ** 6)) // frames_per_chunk
+        by_bytes = slot_bytes // max(1, frames_per_chunk * int(hw[0]) * int(hw[1]) * 3)
+        return max(1, min(by_pass, by_bytes))
+
     def _group_search(self, emb_all: torch.Tensor, counts: List[int]):
         """Neighbours of every frame of a look-ahead group in ONE pass, equal to the chunk-by-chunk loop of
         src/pipeline/vlm_extractor.py:44-74 (search chunk i against everything before it, then append it):
@@ -218,14 +234,16 @@ class FrameEmbeddingExtractor:
                                             video_cfg.frames_per_chunk)
             results = []
             result_lines: List[str] = []      # results[i] as JSON text (finish)
-            # Look-ahead groups (config.encoder.look_ahead_chunks, default 1 = the reference's one chunk at a time,
+            # Look-ahead groups (config.encoder.look_ahead_chunks, default 1 = the reference's one chunk at a time, 0 = auto,
             # :44-74): the frames of N consecutive chunks go through ONE encoder call - the encoder fills the chip only
             # from a few hundred frames up - and then every chunk of the group, in chunk order, gets its own top-k
             # against the memory as it stands (chunks < i, the group's earlier chunks included) followed by its own
             # append: the same neighbours and the same rows as N = 1, bit for bit (an embedding does not depend on the
             # batch it was computed in: tests/test_encoder_gpu.py::test_bench_size_batches...).  Results are read
             # back once per group, AFTER the next group's launches are queued, so the GPU never waits for the host.
-            L = max(1, int(cfgmod.section(self.config, "encoder", cfgmod.ENCODER_DEFAULTS).look_ahead_chunks))
+            L = int(cfgmod.section(self.config, "encoder", cfgmod.ENCODER_DEFAULTS).look_ahead_chunks)
+            if L <= 0:
+                L = self._auto_look_ahead(src, int(video_cfg.frames_per_chunk))
             # the first groups ramp up (1/8, 1/4, 1/2 of L): the GPU starts on a small group while the host is still
             # reading the first full one (grouping never changes a result, only when work is launched)
             groups, i, size = [], 0, max(1, L // 8)

@@ -101,7 +101,7 @@ def test_look_ahead_groups_change_nothing_but_the_time(tmp_path, monkeypatch, me
     np.savez(clip, frames=frames, fps=np.float64(10.0))           # 9 chunks of 10 frames, 7 picked per chunk; 5 left over
     runs = {}
     enc = None
-    for n in (1, 4):
+    for n in (1, 4, 0):      # 0 = sized from the encoder's pass (here: more chunks than the clip has, one ramp of groups)
         cfg = C.from_dict({
             "video": {"chunk_size_seconds": 1.0, "frames_per_chunk": 7},
             "encoder": {"arch": "vit_b16_2l", "dtype": "f16", "seed": 3, "top_k": 4, "look_ahead_chunks": n},
@@ -118,6 +118,7 @@ def test_look_ahead_groups_change_nothing_but_the_time(tmp_path, monkeypatch, me
     assert len(runs[1][0]) == 9 and runs[1][2] == 63
     assert runs[1][0] == runs[4][0]
     assert torch.equal(runs[1][1], runs[4][1]) and runs[1][2] == runs[4][2]
+    assert runs[1][0] == runs[0][0] and torch.equal(runs[1][1], runs[0][1]) and runs[1][2] == runs[0][2]
     assert any(fr for r in runs[4][0] for fr in r["similar"])
 
 

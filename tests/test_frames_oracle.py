@@ -132,7 +132,7 @@ def test_cv2_source_branch_with_a_stand_in_module(tmp_path, monkeypatch):
             self.pos = 0
 
         def get(self, prop):
-            return {5: 25.0, 7: float(len(frames))}[prop]
+            return {5: 25.0, 7: float(len(frames)), 3: 6.0, 4: 4.0}[prop]
 
         def set(self, prop, value):
             assert prop == 1
@@ -145,10 +145,11 @@ def test_cv2_source_branch_with_a_stand_in_module(tmp_path, monkeypatch):
         def release(self):
             log.append(("release",))
 
-    fake = types.SimpleNamespace(VideoCapture=FakeCapture, CAP_PROP_POS_FRAMES=1, CAP_PROP_FPS=5, CAP_PROP_FRAME_COUNT=7)
+    fake = types.SimpleNamespace(VideoCapture=FakeCapture, CAP_PROP_POS_FRAMES=1, CAP_PROP_FPS=5, CAP_PROP_FRAME_COUNT=7,
+                                 CAP_PROP_FRAME_WIDTH=3, CAP_PROP_FRAME_HEIGHT=4)
     monkeypatch.setitem(sys.modules, "cv2", fake)
     src = X.open_source(str(tmp_path / "clip.mp4"))
-    assert isinstance(src, X._Cv2Source) and src.fps == 25.0 and src.total == 7
+    assert isinstance(src, X._Cv2Source) and src.fps == 25.0 and src.total == 7 and src.frame_hw == (4, 6)
     assert np.array_equal(src.read(5), frames[5]) and src.read(3) is None and src.read(9) is None
     ex = X.FrameEmbeddingExtractor.__new__(X.FrameEmbeddingExtractor)     # only the chunk reader is exercised
     got = ex._read_chunk(src, [0, 3, 6])
@@ -177,3 +178,12 @@ def test_array_source_group_reads(tmp_path):
     _n, plan = X.chunk_plan(30.0, 40, 16 / 30 + 1e-9, 16)
     allp = [i for (_c, _s, _e, idx, _t) in plan for i in idx]
     assert allp == list(range(32)) and np.shares_memory(src.read_many(allp), src.frames)
+    # look_ahead_chunks: 0 sizes the groups from the encoder's pass and a staging budget
+    ex = X.FrameEmbeddingExtractor.__new__(X.FrameEmbeddingExtractor)
+    ex.encoder = type("E", (), {"micro_batch": staticmethod(lambda b: min(b, 883))})()
+    assert src.frame_hw == (6, 5) and ex._auto_look_ahead(src, 16) == 55
+    assert ex._auto_look_ahead(src, 16, slot_bytes=16 * 6 * 5 * 3 * 7 + 1) == 7        # the budget binds
+    big = type("S", (), {"frame_hw": (1080, 1920)})()
+    assert ex._auto_look_ahead(big, 16) == 2                                           # 16 x 6.2 MB per chunk
+    ex.encoder = object()
+    assert ex._auto_look_ahead(src, 16) == 1 and ex._auto_look_ahead(type("S", (), {})(), 16) == 1
