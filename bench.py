@@ -39,15 +39,20 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--chunks-per-step", type=int, default=55,
-                    help="chunks of 16 frames encoded per step per GPU (55 chunks = 880 frames = one encoder pass)")
+    ap.add_argument("--chunks-per-step", type=int, default=110,
+                    help="chunks of 16 frames encoded per step per GPU (110 chunks = 1,760 frames = two encoder passes of "
+                         "880, which the default two-stream schedule runs side by side; 55 = one pass, one stream)")
     ap.add_argument("--memory-rows", type=int, default=None,
                     help="rows of the memory shard per GPU (default: 100,000 = BASELINE configs[1] on one GPU; "
                          "1,048,576 = BASELINE configs[3], 8 M rows over 8 GPUs, when --gpus > 1)")
     ap.add_argument("--no-extractor", action="store_true", help="skip the plugin-path leg (process_video on a host clip)")
     ap.add_argument("--extractor-frames", type=int, default=4096)
     ap.add_argument("--look-ahead-chunks", type=int, default=55, help="chunks per encoder call in the plugin-path leg")
-    ap.add_argument("--no-two-stream", action="store_true", help="skip the two-stream encoder A/B beside the main leg")
+    ap.add_argument("--no-two-stream", action="store_true", help="skip the one-stream A/B beside the main leg")
+    ap.add_argument("--no-ceiling", action="store_true", help="skip the mfma_ceiling leg (vm_probe_mfma)")
+    ap.add_argument("--ceiling-seconds", type=float, default=1.5, help="seconds per vm_probe_mfma variant")
+    ap.add_argument("--no-rccl-world1", action="store_true",
+                    help="skip the one-rank RCCL self-test (tools/rccl_world1.py as a child process)")
     ap.add_argument("--no-c4", action="store_true", help="skip the one-GPU rank-share leg of BASELINE configs[3]")
     ap.add_argument("--c4-world", type=int, default=8, help="ranks of the job whose per-rank step the c4 leg runs")
     ap.add_argument("--topk", type=int, default=10)
@@ -252,6 +257,21 @@ def main():
             print(json.dumps({"metric": "dry-run (launcher self-test, nothing measured)", "value": None,
                               "n_gpus": world, "steps": args.steps, "warmup": args.warmup}))
         return
+    # ---- RCCL on this box, before this process touches the GPU: a child process runs dist.ShardedRetriever on a
+    # one-rank "nccl" group with both all-gathers forced (tools/rccl_world1.py); a hang there is a timeout here
+    rccl_world1 = None
+    if world == 1 and rank == 0 and not args.no_rccl_world1:
+        import subprocess
+        note("rccl world-1 self-test (child process)")
+        try:
+            cp = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_world1.py"), "--rows", "100000",
+                                 "--queries", str(args.chunks_per_step * 16), "--topk", str(args.topk)],
+                                capture_output=True, text=True, timeout=420)
+            lines = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
+            rccl_world1 = json.loads(lines[-1]) if lines else {"ok": False, "error": cp.stderr[-600:]}
+            rccl_world1["exit_code"] = cp.returncode
+        except Exception as exc:   # a timeout or a missing librccl must not cost the run its headline
+            rccl_world1 = {"ok": False, "error": f"{type(exc).__name__}: {exc}"[:600]}
     if args.backend == "gloo":
         local_rank = local_rank % max(1, torch.cuda.device_count())  # rehearsal: ranks may share a GPU
     torch.cuda.set_device(local_rank)
@@ -286,9 +306,9 @@ def main():
     retriever = ShardedRetriever(memory, rank, world)
 
     # synthetic frames resident in HBM: a pool of distinct uint8 frames, cycled through the steps
-    # (distinct frames for every step up to 32 steps: re-embedding a frame plants exact duplicates in the memory, and
+    # (distinct frames for every step up to 40 steps - the timed ones and the event-timed ones behind them: re-embedding a frame plants exact duplicates in the memory, and
     # enough exact ties make a query uncertifiable on the fast path)
-    pool_steps = min(32, args.warmup + args.steps + 1)
+    pool_steps = min(40, args.warmup + 2 * args.steps + 2)
     gf = torch.Generator(device=dev).manual_seed(1234 + rank)
     frame_pool = torch.randint(0, 256, (pool_steps, F, 224, 224, 3), generator=gf, device=dev, dtype=torch.uint8)
 
@@ -305,9 +325,12 @@ def main():
     torch.cuda.synchronize()
 
     # per-kernel breakdown: ONE extra untimed step with every launch bracketed by HIP events (two event records cost
-    # ~7 us per launch here, 12 % of the step, so the timed region records only the dominant kernel's events)
+    # ~7 us per launch here, 12 % of the step).  While per-kernel timing is on, the encoder's default schedule
+    # (VM_SCHED_AUTO, include/vidmem.h) runs ONE stream: with two, a kernel's event duration includes its wait for the
+    # other stream's kernels.
     mb_frames = enc.micro_batch(F)          # frames per encoder pass (csrc/encoder.hip, micro_batch_of)
     passes = -(-F // mb_frames)
+    two_streams = passes >= 2               # what VM_SCHED_AUTO does with this step when timing is off
     per_step_events = passes * (7 * spec["layers"] + 8) + 16
     ctx.profile_enable(per_step_events + 64)
     step(args.warmup)
@@ -319,8 +342,7 @@ def main():
     dom = max(kern_cats, key=lambda kname: sum(breakdown[c][0] for c in kern_cats[kname]))
     ctx.profile_enable(0)
 
-    ctx.profile_enable(0 if args.no_profile else args.steps * per_step_events + 64)
-    ctx.profile_mask(list(kern_cats[dom]))
+    # ---- THE TIMED REGION: exactly args.steps steps of the product's default path (no per-kernel events) -------------
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -331,49 +353,36 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    prof = ctx.profile_read() if not args.no_profile else breakdown
-    ctx.profile_enable(0)
-    ctx.profile_mask(None)
     uncert = retriever.uncertified_total()   # queries the fp32 scan could not certify; redone exhaustively in-step
 
-    # ---- A/B beside the headline: the same steps through an encoder created in its two-stream mode -----------------
-    two_stream = None
-    if rank == 0 and world == 1 and not args.no_two_stream and F >= 32:
-        os.environ["VIDMEM_ENC_DUAL"] = "1"
-        had_mb = os.environ.get("VIDMEM_MICROBATCH")
-        if F <= mb_frames:      # the mode works on consecutive passes of one call: two passes of half the step
-            os.environ["VIDMEM_MICROBATCH"] = str((F + 1) // 2)
-        enc2 = FrameEncoder(spec, weights, dtype="f16", device=local_rank)
-        del os.environ["VIDMEM_ENC_DUAL"]
-        if had_mb is None:
-            os.environ.pop("VIDMEM_MICROBATCH", None)
-        else:
-            os.environ["VIDMEM_MICROBATCH"] = had_mb
-        main_enc = enc
-
-        def step2(i):
-            emb = enc2.embed_frames(frame_pool[i % pool_steps])
-            scores, rows = retriever.search(emb, k)
-            memory.append(emb)
-            return emb
-        same = torch.equal(step2(0), main_enc.embed_frames(frame_pool[0]))
-        for i in range(2):
-            step2(i)
+    # ---- the dominant kernel's launch durations: the SAME steps again with its HIP events on (recorded on the launch
+    # stream; the one-stream schedule, see above).  Also the A/B of the two schedules: same embeddings, bit for bit.
+    one_stream = None
+    prof = breakdown
+    if not args.no_profile:
+        ctx.profile_enable(args.steps * per_step_events + 64)
+        ctx.profile_mask(list(kern_cats[dom]))
         torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        n2 = max(4, args.steps // 2)
-        for i in range(n2):
-            step2(3 + i)
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + 1 + args.steps + i)
         torch.cuda.synchronize()
-        dt2 = (time.perf_counter() - t2) / n2
-        two_stream = {
-            "what": "the same step with the encoder created under VIDMEM_ENC_DUAL=1: micro-batch passes alternate between "
-                    "two internal streams, LayerNorm in its low-register build runs beside the other pass's GEMMs "
-                    "(csrc/encoder.hip vm_encode); off by default because per-kernel event / rocprofv3 durations then "
-                    "include cross-stream waiting",
-            "frames_per_s": F / dt2, "ms_per_step": dt2 * 1e3, "embeddings_bit_identical": bool(same),
-        }
-        del enc2
+        dt1 = (time.perf_counter() - t1) / args.steps
+        prof = ctx.profile_read()
+        ctx.profile_enable(0)
+        ctx.profile_mask(None)
+        if two_streams and not args.no_two_stream:
+            emb_two = enc.embed_frames(frame_pool[0])
+            enc.set_schedule("one_stream")
+            emb_one = enc.embed_frames(frame_pool[0])
+            enc.set_schedule("auto")
+            one_stream = {
+                "what": "the same steps on ONE stream (VM_SCHED_ONE_STREAM is what VM_SCHED_AUTO falls back to while "
+                        "per-kernel timing is on; these are the steps roofline.avg_launch_ms was taken from, the "
+                        "dominant kernel's events recorded: ~0.25 ms per step of event overhead)",
+                "frames_per_s": F / dt1, "ms_per_step": dt1 * 1e3,
+                "embeddings_bit_identical": bool(torch.equal(emb_two, emb_one)),
+            }
 
     t = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
     if world > 1:
@@ -398,9 +407,18 @@ def main():
                                       f"{args.backend} all-gather (rehearsal backend, host-staged)")
                                    + " of queries and candidates") if world > 1 else "single GPU"},
         "queries_per_s": value, "uncertified_queries_redone": uncert,
+        "encoder_schedule": ("two streams (VM_SCHED_AUTO, the default: the step's %d encoder passes of <= %d frames "
+                             "alternate between two internal streams)" % (passes, mb_frames)) if two_streams else
+                            "one stream (a step of one encoder pass)",
     }
-    if two_stream is not None:
-        out["two_stream_encoder"] = two_stream
+    if one_stream is not None:
+        out["one_stream_encoder"] = one_stream
+    if rccl_world1 is not None:
+        out["rccl_world1"] = dict(rccl_world1, what=(
+            "dist.ShardedRetriever on a ONE-rank nccl (= RCCL) process group with both all-gathers forced, in a child "
+            "process before this one touched the GPU (tools/rccl_world1.py): fp16 queries, fp64 scores and int64 rows "
+            "all-gathered on device tensors, result compared bit for bit with the local search.  One rank moves nothing "
+            "over xGMI: the times are RCCL's per-collective overhead, not a link measurement"))
 
     if rank == 0:
         # ---- roofline of the dominant kernel (by total time inside the timed region) ------------------------
@@ -444,6 +462,12 @@ def main():
             "bound": "mfma", "kernel": dom, "achieved": achieved, "peak": MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic,
             "traffic_source": traffic_source,
+            "timing_source": ("HIP events on the launch stream over %d steps run right after the timed region on the "
+                              "one-stream schedule (one_stream_encoder); the timed region itself runs two streams, where "
+                              "an event pair also spans the wait for the other stream's kernels" % args.steps)
+                             if (two_streams and not args.no_profile) else
+                             ("HIP events on the launch stream over %d steps of the same schedule, run right after the "
+                              "timed region" % args.steps if not args.no_profile else "the one event-bracketed step"),
             "traffic_note": "HBM/fabric bytes per launch = 2*FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc "
                             "passes of this bench (traffic_source); algorithmic_bytes = operands + output once per "
                             "launch",
@@ -460,6 +484,31 @@ def main():
                                  if enc_ms > 0 else None)
         out["encoder_gflop_per_frame"] = {"executed": specs.flops_per_frame(spec, executed=True) / 1e9,
                                           "every_row": specs.flops_per_frame(spec) / 1e9}
+
+    # ---- what this GPU sustains on 16-bit MFMA work, here and now (vm_probe_mfma) ---------------------
+    # The chip lowers its clock under matrix load: the data sheet's 2.5 PFLOP/s is not what ANY kernel reaches on random
+    # operands.  Three synthetic loops - registers only; + the GEMM tile's fragment reads; + its L2 -> LDS staging -
+    # put a measured ceiling beside the fraction of the data-sheet peak.
+    if rank == 0 and world == 1 and not args.no_ceiling:
+        note("mfma ceiling leg")
+        secs = args.ceiling_seconds
+        names = ("registers_only", "with_fragment_reads", "with_fragment_reads_and_staging")
+        ceil = {n: ctx.probe_mfma(v, secs) for v, n in enumerate(names)}
+        zero = ctx.probe_mfma(2, min(secs, 1.0), zero_operands=True)
+        out["mfma_ceiling"] = {
+            "what": "vm_probe_mfma (csrc/probe.hip): v_mfma_f32_16x16x32_f16 loops with the operand pattern of the GEMM's "
+                    "128 x 64 wave tile, two waves per SIMD on every CU, RANDOM operands, %.1f s each: (0) registers only, "
+                    "(1) + 12 conflict-free ds_read_b128 per 32 MFMAs, (2) + 4 KiB of LDS-DMA per wave and 32 MFMAs out "
+                    "of L2 = the K loop of gemm256p_kernel with no epilogue, barrier, tile boundary, miss or store" % secs,
+            "unit": "TFLOP/s", **ceil,
+            "with_fragment_reads_and_staging_zero_operands": zero,
+            "data_sheet_peak": MFMA_PEAK_TFLOPS,
+        }
+        sustained = ceil["with_fragment_reads_and_staging"]
+        out["roofline"]["sustained_ceiling"] = sustained
+        out["roofline"]["frac_of_sustained"] = out["roofline"]["achieved"] / sustained if sustained > 0 else None
+        out["roofline"]["sustained_note"] = ("sustained_ceiling = mfma_ceiling.with_fragment_reads_and_staging, measured "
+                                             "in this run on this GPU; frac stays achieved / the 2.5 PFLOP/s data sheet")
 
     # ---- kNN half of the metric: Q=16 queries/launch over a 1M x 768 index (single GPU part of every rank 0) ----
     if rank == 0 and world == 1 and not args.no_knn:
@@ -572,6 +621,17 @@ def main():
             "uncertified_queries_redone": redone4, "uncertified_queries_redone_in_the_profiled_step": redone4_prof,
             "same_shard_own_queries_only_ms_per_step": ms_alone,
             "projected_weak_scaling_efficiency": eff, "projected_speedup_at_world": eff * W4,
+            # the two all-gathers of the real job, as fields: what one rank ends up holding per step, what crosses each
+            # of its links (one peer's share), and what that costs at the per-link rate of the 8-GPU xGMI mesh
+            "all_gather_bytes_per_rank_step": {"queries_f16": Q4 * D * 2, "candidates_f64_i64": W4 * Q4 * k * 16},
+            "all_gather_bytes_per_link_step": {"queries_f16": F * D * 2, "candidates_f64_i64": Q4 * k * 16},
+            "all_gather_expected_ms_per_step": {
+                "assumption": "fully connected xGMI, ~153 GB/s per link and direction (SURVEY.md 5), every peer's share "
+                              "over its own link in parallel, + ~30 us of RCCL launch latency per collective (three "
+                              "collectives per step: queries, scores, rows); NOT measured",
+                "queries_f16": (F * D * 2) / 153e9 * 1e3 + 0.03,
+                "candidates_f64_i64": (Q4 * k * 16) / 153e9 * 1e3 + 0.06,
+            },
             "projection_note": f"PROJECTED, NOT MEASURED: (step of one GPU alone on the same {R4}-row shard, {F} queries) / "
                                f"(this rank-share step); excludes the two all-gathers of the real job "
                                f"({Q4 * D * 2 / 1e6:.1f} MB of queries + {Q4 * k * 16 / 1e6:.1f} MB of candidates per rank "
@@ -779,8 +839,9 @@ def main():
         # (a launch's traffic depends on the frames per encoder pass, not on how many passes a timing holds)
         c3_traffic, c3_src = pmc_traffic("void (anonymous namespace)::gemm256p_kernel<1, 0, 0>", f"mb{mb3}", "c3")
         out["c3"] = {
-            "workload": f"BASELINE configs[2]: CLIP-ViT-L/14-336 bf16, {F3} frames per timing ({passes3} encoder "
-                        f"passes of {mb3}); top-{k3} of 16 queries over {M3} x {D3} bf16",
+            "workload": f"BASELINE configs[2]: CLIP-ViT-L/14-336 bf16, {F3} of configs[2]'s 32,768 frames per timing "
+                        f"({passes3} encoder passes of {mb3}; a RATE, not the whole job); top-{k3} of 16 queries over "
+                        f"{M3} x {D3} bf16",
             "frames_per_s": F3 / dt_enc, "encoder_tflops": F3 / dt_enc * specs.flops_per_frame(spec3, executed=True) / 1e12,
             "knn_queries_per_s": 16 / dt_knn, "knn_scan_GBps": M3 * D3 * 2 / dt_knn / 1e9,
             "uncertified_queries_redone": mem3.uncertified_count,

@@ -48,7 +48,8 @@ int vm_init(int device, vm_ctx **out);
 void vm_destroy(vm_ctx *ctx);
 const char *vm_last_error(vm_ctx *ctx);
 /* ABI version of this header (bumped on any signature change; 3: vm_encode_micro_batch, VM_PROF_GEMM_CLS - the arrays
- * vm_profile_read fills grew to 14 entries). */
+ * vm_profile_read fills grew to 14 entries; 4: vm_encoder_set_option / vm_encoder_get_option replace the environment
+ * variables an encoder used to read when it was created, vm_probe_mfma, vm_topk_select). */
 int vm_abi_version(void);
 
 /* ---- frame preprocessing ------------------------------------------------------------------------------
@@ -96,15 +97,31 @@ typedef struct vm_encoder_desc {
 int vm_encoder_create(vm_ctx *ctx, const vm_encoder_desc *desc, const void *const *weights_host, int n_weights,
                       vm_encoder **out);
 void vm_encoder_destroy(vm_encoder *enc);
+/* Per-encoder options (ABI 4).  The release library reads NO environment variable: what a deployment may choose is
+ * set here, on the handle, between calls (not while a vm_encode of this encoder is being captured or is in flight).
+ * Every value of every option produces the same embeddings bit for bit (tests/test_encoder_gpu.py).
+ *   VM_ENC_OPT_SCHEDULE     vm_encoder_schedule.  TWO_STREAMS: consecutive micro-batch passes of one vm_encode call
+ *                           alternate between two internal streams (forked from / joined to the caller's stream inside
+ *                           the call, still capturable; one workspace per stream), so that one pass's bandwidth-bound
+ *                           LayerNorms run beside the other pass's matrix-bound GEMMs.  ONE_STREAM: every kernel on the
+ *                           caller's stream.  AUTO (default): TWO_STREAMS for calls of two or more passes, except
+ *                           while vm_profile_enable(ctx, > 0) is in force - with two streams a kernel's event
+ *                           duration includes its wait for the other stream's kernels, so timing runs take one stream.
+ *   VM_ENC_OPT_MICRO_BATCH  frames per pass; 0 (default) = chosen by the library (see vm_encode_micro_batch).
+ *   VM_ENC_OPT_LAST_LAYER   which rows the LAST layer computes behind its keys and values: 3 (default) = the CLS rows
+ *                           only (the embedding is pooled from them), 1 = CLS rows behind the attention, 0 = every row. */
+enum vm_encoder_option { VM_ENC_OPT_SCHEDULE = 0, VM_ENC_OPT_MICRO_BATCH = 1, VM_ENC_OPT_LAST_LAYER = 2 };
+enum vm_encoder_schedule { VM_SCHED_AUTO = 0, VM_SCHED_ONE_STREAM = 1, VM_SCHED_TWO_STREAMS = 2 };
+int vm_encoder_set_option(vm_encoder *enc, int option, int value);
+int vm_encoder_get_option(const vm_encoder *enc, int option);   /* negative = vm_status */
 int vm_encoder_tokens(const vm_encoder *enc);    /* patches + 1                        */
 int vm_encoder_patch_k(const vm_encoder *enc);   /* 3*patch*patch rounded up to 64     */
 int vm_encoder_out_dim(const vm_encoder *enc);   /* proj_dim ? proj_dim : hidden       */
 size_t vm_encode_workspace_bytes(const vm_encoder *enc, int B);
 /* Frames vm_encode runs per pass for a call with B frames (it walks B in micro-batches: a whole number of GEMM tile
  * rounds, and - for sequences that take one attention workgroup per (frame, head) - of attention rounds).
- * An encoder created with VIDMEM_ENC_DUAL=1 in the environment runs consecutive passes of a call on two internal
- * streams (forked from / joined to the caller's stream inside vm_encode, still capturable); vm_encode_workspace_bytes
- * then returns twice the single-pass size for calls of more than one pass.  Same embeddings either way. */
+ * vm_encode_workspace_bytes returns twice the single-pass size for calls of more than one pass unless the schedule is
+ * VM_SCHED_ONE_STREAM (one workspace per internal stream); a call that is handed less runs on one stream. */
 int vm_encode_micro_batch(const vm_encoder *enc, int B);
 /* patches: [B, tokens-1, patch_k] dtype (vm_preprocess, PATCHES layout).  out_emb: [B, out_dim] dtype.
  * l2_normalise: divide each embedding by its L2 norm (fp32) before the cast. */
@@ -178,6 +195,14 @@ int vm_topk_cosine_exact(vm_memory *mem, const void *queries, int Q, int k, int 
  * (:497), so `>= compression_threshold` decisions cannot flip on a 16-bit rounding. */
 int vm_cosine_exact(vm_ctx *ctx, const void *queries, int Q, const void *rows, int64_t S, int D, int dtype,
                     double *out, void *stream);
+/* The k best columns of every row of an all-pairs score matrix (vm_cosine_exact's output), by the order relation of
+ * vm_topk_cosine: (score descending, column ascending).  scores [Q,S] fp64; col_limit (device int64 [Q], may be NULL):
+ * query q ranks only columns < col_limit[q].  out_rows = row_base + column, -1 / 0.0 padded.  With vm_cosine_exact
+ * and vm_topk_merge this ranks the frames of a look-ahead group against the group's own EARLIER chunks, rows that are
+ * about to be appended: what the reference's chunk-by-chunk loop would have stored by the time each chunk is searched
+ * (src/pipeline/vlm_extractor.py:44-74; the same stable sort as src/components/pre_llm_injector.py:369). */
+int vm_topk_select(vm_ctx *ctx, const double *scores, int Q, int64_t S, const int64_t *col_limit, int k,
+                   int64_t row_base, double *out_scores, int64_t *out_rows, void *stream);
 /* Merge `parts` per-shard results (each [Q,k], sorted as above, -1 padded) into the global top-k:
  * the step after the RCCL all-gather (and the cross-query max-merge input of pre_llm_injector.py:238-249).
  * scores [parts,Q,k] fp64, rows [parts,Q,k] int64. */
@@ -202,6 +227,19 @@ int vm_profile_read(vm_ctx *ctx, double *total_ms_host /*[VM_PROF_NCAT]*/, int64
 /* Restrict event recording to the categories whose bit (1u << vm_prof_cat) is set (default: all).  Two event
  * records cost several microseconds per launch on this stack, so a timed run enables only the kernel it reports. */
 int vm_profile_mask(vm_ctx *ctx, uint32_t category_mask);
+
+/* What this GPU sustains on 16-bit MFMA work, measured here and now (bench.py's `mfma_ceiling`).  The
+ * chip lowers its clock under matrix load, so the 2.5 PFLOP/s of the data sheet is not what any kernel can reach on
+ * random operands; these loops put a number on what can.  Runs back-to-back launches of a synthetic loop for about
+ * `seconds` on `stream`, synchronises, and writes the mean rate in TFLOP/s to *tflops_host.
+ *   variant 0: register-only v_mfma_f32_16x16x32_f16 loop with the operand pattern of a 128 x 64 wave tile, two waves
+ *              per SIMD on every CU - no LDS, no memory;
+ *   variant 1: + the fragment reads of the 256 x 256 GEMM tile (12 conflict-free ds_read_b128 per 32 MFMAs);
+ *   variant 2: + its staging (4 KiB of LDS-DMA per wave and 32 MFMAs out of an L2-resident buffer, counted wait):
+ *              the GEMM's K loop with no epilogue, barrier, tile boundary, miss or store.
+ * zero_operands = 1 fills the operands with zeros (the same cycles at the clock an idle data path allows).
+ * No reference counterpart (the reference has no kernels). */
+int vm_probe_mfma(vm_ctx *ctx, int variant, int zero_operands, double seconds, double *tflops_host, void *stream);
 
 #ifdef __cplusplus
 }

@@ -616,16 +616,8 @@ int launch_long(vm_ctx *ctx, const uint16_t *qkv, uint16_t *out, int B, int T, i
     const size_t lds = (size_t)NT * 16 * 128 * 2;
     // 16 waves (4 per SIMD; the kernel needs ~80 VGPRs).  Measured on the two-pass build: 21.1 ms vs 27.0 ms with 8
     // waves per 256-frame CLIP-L pass
-    static int online_env = -1;
-    if (online_env < 0) {
-        const char *e = getenv("VIDMEM_ATTN_ONLINE");
-        online_env = e ? atoi(e) : 1;
-    }
-    static int pair_env = -1;
-    if (pair_env < 0) {
-        const char *e = getenv("VIDMEM_ATTN_PAIR");   // waves of the two-tiles-per-walk kernel; 0 = one tile per walk
-        pair_env = e ? atoi(e) : 12;
-    }
+    static const int online_env = (int)VM_DEV_ENV("ATTN_ONLINE", 1);
+    static const int pair_env = (int)VM_DEV_ENV("ATTN_PAIR", 12);   // waves of the two-tiles-per-walk kernel; 0 = one tile per walk
     vm_prof_scope prof(ctx, VM_PROF_ATTENTION, st);
     if (online_env && pair_env > 0) {
         const int ql = qt_lim < NT ? qt_lim : NT;
@@ -828,11 +820,7 @@ template <int DT, int NT, bool EXACT>
 int launch_stream(vm_ctx *ctx, const uint16_t *qkv, uint16_t *out, int B, int T, int heads, hipStream_t st, int qt_lim) {
     // 13 compute waves (one query tile each, four waves per SIMD at <= 128 registers) + the loader; VIDMEM_ATTN_CW=8:
     // eight compute waves with up to two tiles each (168 registers)
-    static int cw_env = -1;
-    if (cw_env < 0) {
-        const char *e = getenv("VIDMEM_ATTN_CW");
-        cw_env = e ? atoi(e) : 13;
-    }
+    static const int cw_env = (int)VM_DEV_ENV("ATTN_CW", 13);
     if (cw_env == 8) return launch_stream_cw<DT, NT, EXACT, 8>(ctx, qkv, out, B, T, heads, st, qt_lim);
     return launch_stream_cw<DT, NT, EXACT, 13>(ctx, qkv, out, B, T, heads, st, qt_lim);
 }

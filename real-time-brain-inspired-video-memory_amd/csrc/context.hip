@@ -3,7 +3,7 @@
 
 static thread_local char g_init_err[256] = "";
 
-extern "C" int vm_abi_version(void) { return 3; }
+extern "C" int vm_abi_version(void) { return 4; }
 
 extern "C" int vm_init(int device, vm_ctx **out) {
     if (!out) return VM_ERR_INVALID;

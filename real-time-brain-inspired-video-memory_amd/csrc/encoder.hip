@@ -386,11 +386,7 @@ int vm_resid_layernorm(vm_ctx *ctx, int dtype, float *x32, const uint16_t *delta
         return VM_OK;
     }
     // rows that together exceed the 32 MiB of L2 several times over stream through with the non-temporal policy
-    static int nt_env = -1;
-    if (nt_env < 0) {
-        const char *e = getenv("VIDMEM_LN_NT");
-        nt_env = e ? atoi(e) : 1;
-    }
+    static const int nt_env = (int)VM_DEV_ENV("LN_NT", 1);
     const bool nt = nt_env && (size_t)rows * H * 4 > ((size_t)64 << 20);
 #define RLN16(V) resid_layernorm_kernel<VM_F16, V, RPW, false><<<blocks, 256, 0, st>>>(x32, delta16, deltaB16, write_x, gamma, beta, eps, out16, rows, H, rstride)
 #define RLNB16(V) resid_layernorm_kernel<VM_BF16, V, RPW, false><<<blocks, 256, 0, st>>>(x32, delta16, deltaB16, write_x, gamma, beta, eps, out16, rows, H, rstride)
@@ -455,12 +451,12 @@ struct vm_encoder {
     uint16_t *patch_w, *proj_w;
     float *patch_b, *cls, *pos, *pre_g, *pre_b, *ln_g, *ln_b;
     LayerW *layers;
-    int micro_batch;
-    int cls_last;   // VIDMEM_CLS_LAST at creation (developer A/B; default 3): see vm_encode's last layer
-    // two-stream mode (VIDMEM_ENC_DUAL=1 at creation, default off): consecutive micro-batch passes of one vm_encode
-    // call alternate between two internal streams, so that the bandwidth-bound LayerNorms of one pass (low-register
-    // build) run beside the matrix-bound GEMMs of the other; see vm_encode
-    int dual;
+    int micro_batch;   // VM_ENC_OPT_MICRO_BATCH: frames per pass, 0 = auto
+    int cls_last;      // VM_ENC_OPT_LAST_LAYER (default 3): see vm_encode's last layer
+    // VM_ENC_OPT_SCHEDULE.  Two-stream schedule: consecutive micro-batch passes of one vm_encode call alternate between
+    // two internal streams, so that the bandwidth-bound LayerNorms of one pass (low-register build) run beside the
+    // matrix-bound GEMMs of the other; see vm_encode.  AUTO = two streams unless per-kernel timing is on.
+    int schedule;
     hipStream_t side[2];
     hipEvent_t ev_fork, ev_join[2];
 };
@@ -494,24 +490,19 @@ extern "C" int vm_encoder_create(vm_ctx *ctx, const vm_encoder_desc *desc, const
         delete e;
         return vm_fail(ctx, VM_ERR_UNSUPPORTED, "%d tokens per frame > 592", e->tokens);
     }
-    const char *mb = getenv("VIDMEM_MICROBATCH");
-    e->micro_batch = mb ? atoi(mb) : 0;
-    const char *cl = getenv("VIDMEM_CLS_LAST");
-    e->cls_last = cl ? atoi(cl) : 3;
-    {
-        const char *du = getenv("VIDMEM_ENC_DUAL");
-        e->dual = du ? atoi(du) : 0;
-        if (e->dual) {
-            hipError_t he = hipSuccess;
-            for (int i = 0; i < 2 && he == hipSuccess; ++i) {
-                he = hipStreamCreateWithFlags(&e->side[i], hipStreamNonBlocking);
-                if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming);
-            }
-            if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
-            if (he != hipSuccess) {
-                delete e;
-                return vm_fail(ctx, VM_ERR_HIP, "two-stream mode: %s", hipGetErrorString(he));
-            }
+    e->micro_batch = 0;
+    e->cls_last = 3;
+    e->schedule = VM_SCHED_AUTO;
+    {   // the two internal streams of the two-stream schedule (a few hundred bytes of driver state when never used)
+        hipError_t he = hipSuccess;
+        for (int i = 0; i < 2 && he == hipSuccess; ++i) {
+            he = hipStreamCreateWithFlags(&e->side[i], hipStreamNonBlocking);
+            if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming);
+        }
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
+        if (he != hipSuccess) {
+            vm_encoder_destroy(e);   // destroys whatever was created so far
+            return vm_fail(ctx, VM_ERR_HIP, "encoder streams: %s", hipGetErrorString(he));
         }
     }
     const size_t H = d.hidden, M = d.mlp;
@@ -594,16 +585,45 @@ extern "C" int vm_encoder_create(vm_ctx *ctx, const vm_encoder_desc *desc, const
 
 extern "C" void vm_encoder_destroy(vm_encoder *e) {
     if (!e) return;
-    if (e->dual) {
-        for (int i = 0; i < 2; ++i) {
-            if (e->side[i]) (void)hipStreamDestroy(e->side[i]);
-            if (e->ev_join[i]) (void)hipEventDestroy(e->ev_join[i]);
-        }
-        if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    for (int i = 0; i < 2; ++i) {
+        if (e->side[i]) (void)hipStreamDestroy(e->side[i]);
+        if (e->ev_join[i]) (void)hipEventDestroy(e->ev_join[i]);
     }
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->blob) (void)hipFree(e->blob);
     delete[] e->layers;
     delete e;
+}
+
+extern "C" int vm_encoder_set_option(vm_encoder *e, int option, int value) {
+    if (!e) return VM_ERR_INVALID;
+    switch (option) {
+        case VM_ENC_OPT_SCHEDULE:
+            if (value != VM_SCHED_AUTO && value != VM_SCHED_ONE_STREAM && value != VM_SCHED_TWO_STREAMS)
+                return vm_fail(e->ctx, VM_ERR_INVALID, "VM_ENC_OPT_SCHEDULE: %d", value);
+            e->schedule = value;
+            return VM_OK;
+        case VM_ENC_OPT_MICRO_BATCH:
+            if (value < 0) return vm_fail(e->ctx, VM_ERR_INVALID, "VM_ENC_OPT_MICRO_BATCH: %d", value);
+            e->micro_batch = value;
+            return VM_OK;
+        case VM_ENC_OPT_LAST_LAYER:
+            if (value != 0 && value != 1 && value != 3)
+                return vm_fail(e->ctx, VM_ERR_INVALID, "VM_ENC_OPT_LAST_LAYER: %d (0, 1 or 3)", value);
+            e->cls_last = value;
+            return VM_OK;
+        default:
+            return vm_fail(e->ctx, VM_ERR_INVALID, "unknown encoder option %d", option);
+    }
+}
+extern "C" int vm_encoder_get_option(const vm_encoder *e, int option) {
+    if (!e) return VM_ERR_INVALID;
+    switch (option) {
+        case VM_ENC_OPT_SCHEDULE: return e->schedule;
+        case VM_ENC_OPT_MICRO_BATCH: return e->micro_batch;
+        case VM_ENC_OPT_LAST_LAYER: return e->cls_last;
+        default: return VM_ERR_INVALID;
+    }
 }
 
 extern "C" int vm_encoder_tokens(const vm_encoder *e) { return e ? e->tokens : 0; }
@@ -665,7 +685,8 @@ extern "C" size_t vm_encode_workspace_bytes(const vm_encoder *e, int B) {
     if (!e || B <= 0) return 0;
     const int mb = micro_batch_of(e, B);
     const size_t one = carve(e, mb, nullptr).bytes;
-    return (e->dual && B > mb) ? 2 * one : one;   // two-stream mode: one workspace per stream
+    // the two-stream schedule keeps one workspace per stream (calls of more than one pass)
+    return (e->schedule != VM_SCHED_ONE_STREAM && B > mb) ? 2 * one : one;
 }
 
 extern "C" int vm_encode_micro_batch(const vm_encoder *e, int B) { return e && B > 0 ? micro_batch_of(e, B) : 0; }
@@ -685,13 +706,12 @@ extern "C" int vm_encode(vm_encoder *e, const void *patches, int B, void *out_em
     const vm_encoder_desc &d = e->d;
     const int H = d.hidden, T = e->tokens, P = e->patches, dt = d.dtype;
     const int act_epi = d.act == VM_ACT_QUICK_GELU ? EPI_QGELU16 : EPI_GELU16;
-    // VIDMEM_CLS_LAST, read when the encoder is created (developer A/B): bit 0 = projection / LN2 / MLP of the last
-    // layer on the CLS rows only, bit 1 = also only the CLS rows' queries and query tile in its attention; 0 =
-    // everything on every row
+    // VM_ENC_OPT_LAST_LAYER: bit 0 = projection / LN2 / MLP of the last layer on the CLS rows only, bit 1 = also only
+    // the CLS rows' queries and query tile in its attention; 0 = everything on every row (same embeddings, tests)
     const int cls_env = e->cls_last;
     const bool cls_only = (cls_env & 1) != 0;
 
-    // Two-stream mode (e->dual, VIDMEM_ENC_DUAL=1 when the encoder is created; default off).  Consecutive micro-batch
+    // Two-stream schedule (VM_ENC_OPT_SCHEDULE; the default for calls of two or more passes).  Consecutive micro-batch
     // passes of a call alternate between two internal streams (fork behind the caller's stream, join before returning;
     // one workspace per stream) and the residual + LayerNorm passes use their low-register build - 58 VGPRs, no LDS:
     // the only kernel of the encoder that is admitted NEXT TO the persistent GEMM, which leaves 64 VGPRs per SIMD and
@@ -699,15 +719,17 @@ extern "C" int vm_encode(vm_encoder *e, const void *patches, int B, void *out_em
     // 25.7 k -> 26.8 k frames/s (+4.3 %), CLIP-L/14-336 bf16 2,615 -> 2,703 (+3.3 %); with the ordinary LayerNorm on
     // two streams +-0; with every matrix kernel of both passes on ONE stream and only the LayerNorms on a side stream
     // between events (tools/experiments/encoder_kernel_granularity_pipeline.patch) -1.3 %: the GEMM launches stretch
-    // by more than the LayerNorm time they cover.  It is off by default because HIP-event (and rocprofv3) kernel
-    // durations then include the time a kernel waits for the other stream's GEMM to leave the CUs: per-kernel
-    // rooflines can no longer be read from them.
+    // by more than the LayerNorm time they cover.  With two streams a kernel's HIP-event (and rocprofv3) duration
+    // includes the time it waits for the other stream's GEMM to leave the CUs, so VM_SCHED_AUTO falls back to ONE
+    // stream while per-kernel timing is enabled on the context (vm_profile_enable > 0): same embeddings, clean timings.
     struct Pass {
         int b0, nb, rows;
         Ws ws;
         const uint16_t *pend_proj, *pend_fc2;   // branch outputs not yet folded into x32 (previous layer's)
     };
-    const bool dual = e->dual && B > mb && workspace_bytes >= 2 * ws0.bytes;
+    const bool timing = ctx->prof_ev != nullptr;
+    const bool dual = B > mb && workspace_bytes >= 2 * ws0.bytes &&
+                      (e->schedule == VM_SCHED_TWO_STREAMS || (e->schedule == VM_SCHED_AUTO && !timing));
     const Ws ws1 = dual ? carve(e, mb, (char *)workspace + ws0.bytes) : ws0;
     hipStream_t st0 = st;
     int rc = VM_OK;
@@ -809,30 +831,38 @@ extern "C" int vm_encode(vm_encoder *e, const void *patches, int B, void *out_em
                        l2_normalise, dst, p.nb, T, H, st);
     };
 #define VM_TRY(x) do { if ((rc = (x)) != VM_OK) return rc; } while (0)
-    int pass = 0;
-    for (int b0 = 0; b0 < B; ++pass) {
-        Pass A;
-        A.b0 = b0;
-        A.nb = B - b0 < mb ? B - b0 : mb;
-        A.rows = A.nb * T;
-        A.ws = dual && (pass & 1) ? ws1 : ws0;
-        st = dual ? e->side[pass & 1] : st0;    // the stage lambdas launch on `st`
-        VM_TRY(embed(A));
-        for (int l = 0; l < d.layers; ++l) {
-            VM_TRY(ln1(A, l));
-            VM_TRY(attn_block(A, l));
-            VM_TRY(ln2(A, l));
-            VM_TRY(mlp_block(A, l));
+    auto run_passes = [&]() -> int {
+        int pass = 0;
+        for (int b0 = 0; b0 < B; ++pass) {
+            Pass A;
+            A.b0 = b0;
+            A.nb = B - b0 < mb ? B - b0 : mb;
+            A.rows = A.nb * T;
+            A.ws = dual && (pass & 1) ? ws1 : ws0;
+            st = dual ? e->side[pass & 1] : st0;    // the stage lambdas launch on `st`
+            VM_TRY(embed(A));
+            for (int l = 0; l < d.layers; ++l) {
+                VM_TRY(ln1(A, l));
+                VM_TRY(attn_block(A, l));
+                VM_TRY(ln2(A, l));
+                VM_TRY(mlp_block(A, l));
+            }
+            VM_TRY(pool(A));
+            b0 += A.nb;
         }
-        VM_TRY(pool(A));
-        b0 += A.nb;
-    }
-    if (dual) {   // join: the caller's stream continues behind both
-        for (int i = 0; i < 2; ++i) {
-            VM_HIP(ctx, hipEventRecord(e->ev_join[i], e->side[i]));
-            VM_HIP(ctx, hipStreamWaitEvent(st0, e->ev_join[i], 0));
-        }
-    }
+        return VM_OK;
+    };
 #undef VM_TRY
-    return VM_OK;
+    rc = run_passes();
+    if (dual) {
+        // join, ALSO after a failed launch: kernels already queued on the side streams still use the workspaces, so the
+        // caller's stream must not run past them (and a stream capture must not be left with unjoined forks)
+        for (int i = 0; i < 2; ++i) {
+            hipError_t he = hipEventRecord(e->ev_join[i], e->side[i]);
+            if (he == hipSuccess) he = hipStreamWaitEvent(st0, e->ev_join[i], 0);
+            if (he != hipSuccess && rc == VM_OK)
+                rc = vm_fail(ctx, VM_ERR_HIP, "vm_encode: joining the internal streams failed: %s", hipGetErrorString(he));
+        }
+    }
+    return rc;
 }

@@ -64,10 +64,14 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
 
 // EPI_DELTA16 stores a bf16 encoder's residual-branch outputs as fp16 (vm_kernels.h): values beyond fp16's range - the
 // outlier activations a bf16 checkpoint may have been chosen for - saturate at +-65504 instead of becoming inf (which
-// the LayerNorm behind it would turn into a NaN row).  v_med3_f32: one instruction per element, bf16 encoders only.
-__device__ __forceinline__ f32x2 sat_f16(f32x2 v) {
-    return f32x2{__builtin_amdgcn_fmed3f(v.x, -65504.0f, 65504.0f), __builtin_amdgcn_fmed3f(v.y, -65504.0f, 65504.0f)};
+// the LayerNorm behind it would turn into a NaN row).  A NaN stays a NaN (v_med3_f32 alone would return -65504 for
+// it and hide a broken activation behind a finite, wrong embedding): v_med3_f32 + v_cmp_u_f32 + v_cndmask per element,
+// bf16 encoders only, in epilogues that are not VALU-bound.
+__device__ __forceinline__ float sat_f16_1(float v) {
+    const float c = __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);
+    return __builtin_isnan(v) ? v : c;
 }
+__device__ __forceinline__ f32x2 sat_f16(f32x2 v) { return f32x2{sat_f16_1(v.x), sat_f16_1(v.y)}; }
 
 // Element index of out16[t, f]: row-major [M, ldo], or head-major [N/64][M][64] (each 64-feature head a contiguous
 // [M, 64] block: what the attention kernel streams; see vm_kernels.h).
@@ -853,11 +857,7 @@ int g_variant = 0;  // 0 auto, 1 force 128^2, 2 force 256^2 one tile per block, 
 
 template <int DT, int EPI>
 int launch_epi(vm_ctx *ctx, const GemmArgs &g, hipStream_t st) {
-    static int env_variant = -1;
-    if (env_variant < 0) {
-        const char *e = getenv("VIDMEM_GEMM");
-        env_variant = e ? atoi(e) : 0;
-    }
+    static const int env_variant = (int)VM_DEV_ENV("GEMM", 0);
     const int variant = g_variant ? g_variant : env_variant;
     const int tiles256 = ((g.M + 255) / 256) * (g.N / 256);
     // the 256 x 256 kernels address a tile through 32-bit byte offsets inside per-tile descriptors (gemm_guard.h)
@@ -968,17 +968,10 @@ int vm_gemm(vm_ctx *ctx, int dtype, const GemmArgs &g, int epi, hipStream_t st) 
     if (a.hm_rows <= 0) a.hm_rows = g.M;
     if (a.hm_stride <= 0) a.hm_stride = 1;
     {   // feature-tile groups of the persistent 256 x 256 kernel (gemm256p_kernel, "Tile order")
-        static long budget = -1;
-        if (budget < 0) {
-            const char *e = getenv("VIDMEM_GEMM_WGROUP_KB");   // weight bytes an XCD's L2 keeps beside the streams; 0 = off
-            budget = e ? atol(e) * 1024 : 2560 * 1024;
-        }
+        // weight bytes an XCD's L2 keeps beside the streams; 0 = off
+        static const long budget = VM_DEV_ENV("GEMM_WGROUP_KB", 2560) * 1024;
         a.fgroup = 0;
-        static int zero_env = -1;
-        if (zero_env < 0) {
-            const char *e = getenv("VIDMEM_GEMM_ZERO");
-            zero_env = e ? atoi(e) : 0;
-        }
+        static const int zero_env = (int)VM_DEV_ENV("GEMM_ZERO", 0);
         a.explicit_zero = zero_env;
         const int tiles_n = g.N / 256;
         const long wtile = 256L * g.K * 2, wall = wtile * tiles_n;

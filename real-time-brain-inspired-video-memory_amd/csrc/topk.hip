@@ -708,11 +708,7 @@ ScanPlan make_plan(const vm_memory *m, int Q, int k) {
     const int nw = SCAN_THREADS / 64;
     const int64_t ntiles = (m->cap + 15) / 16;
     int64_t want = (ntiles + nw - 1) / nw;
-    static int env_per_cu = -1;
-    if (env_per_cu < 0) {
-        const char *e = getenv("VIDMEM_TOPK_BLOCKS_PER_CU");
-        env_per_cu = e ? atoi(e) : 0;
-    }
+    static const int env_per_cu = (int)VM_DEV_ENV("TOPK_BLOCKS_PER_CU", 0);
     const int per_cu = env_per_cu > 0 ? env_per_cu : ((p.cfg.KL <= 16 && p.cfg.QT * p.cfg.KL <= 32) ? 2 : 1);
     // Row-blocks per query group.  One group (Q <= 64): as many as the chip holds, the scan is HBM-bound.  Many
     // groups: the groups already fill the chip, and FEWER row-blocks per group means more rows per lane list, so
@@ -740,11 +736,7 @@ int launch_scan(vm_memory *m, const ScanPlan &p, int nblk, int64_t row_limit, co
         if (e != hipSuccess) return vm_fail(m->ctx, VM_ERR_HIP, "LDS opt-in %zu: %s", p.lds, hipGetErrorString(e));
     }
     const dim3 grid = p.qgroups > 1 ? dim3(nblk * p.qgroups) : dim3(nblk);
-    static int nt_env = -1;
-    if (nt_env < 0) {
-        const char *e = getenv("VIDMEM_TOPK_NT");
-        nt_env = e ? atoi(e) : 1;
-    }
+    static const int nt_env = (int)VM_DEV_ENV("TOPK_NT", 1);
     const int nt_flag = nt_env && row_limit >= m->cap;  // full passes only: the sampling pre-pass's rows are read again
     vm_prof_scope prof(m->ctx, VM_PROF_TOPK_SCAN, st);
     kern<<<grid, SCAN_THREADS, p.lds, st>>>(m->rows, m->rnorm32, (const uint16_t *)queries, m->d_total, m->cap,
@@ -794,12 +786,7 @@ int run_topk_kl(vm_memory *m, const ScanPlan &p, const void *queries, int Q, int
         int *mk = (int *)((char *)cand_cnt + vm_align_up((size_t)p.q_pad * 4, 256));
         float *cand_s = (float *)((char *)mk + vm_align_up((size_t)p.q_pad * 4, 256));
         int *cand_o = (int *)((char *)cand_s + vm_align_up((size_t)p.q_pad * VM_EMIT_CAP * 4, 256));
-        static int growth = -1;
-        if (growth < 0) {
-            const char *e = getenv("VIDMEM_CUT_GROWTH");
-            growth = e ? atoi(e) : 8;
-            if (growth < 2) growth = 2;
-        }
+        static const int growth = VM_DEV_ENV("CUT_GROWTH", 8) < 2 ? 2 : (int)VM_DEV_ENV("CUT_GROWTH", 8);
         // cand_cnt and mk are neighbours: one memset clears both
         hipError_t e = hipMemsetAsync(cand_cnt, 0, 2 * vm_align_up((size_t)p.q_pad * 4, 256), st);
         if (e != hipSuccess) return vm_fail(m->ctx, VM_ERR_HIP, "memset: %s", hipGetErrorString(e));

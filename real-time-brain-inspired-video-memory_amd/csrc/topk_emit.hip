@@ -539,11 +539,7 @@ int launch_emit(vm_memory *m, const void *queries, int Q, const float *thr_s, co
     const int64_t rows = thr_s ? (m->cap < row_limit ? m->cap : row_limit) - row_begin : (int64_t)VM_EMIT_CAP;
     const int64_t ntiles = rows > 0 ? (rows + EM_ROWS - 1) / EM_ROWS : 1;
     if (nbx > ntiles) nbx = (int)ntiles;
-    static int nt_env = -1;
-    if (nt_env < 0) {
-        const char *e = getenv("VIDMEM_TOPK_NT");
-        nt_env = e ? atoi(e) : 1;
-    }
+    static const int nt_env = (int)VM_DEV_ENV("TOPK_NT", 1);
     // one superblock, and a pass that reads (nearly) the whole memory: every row byte is read once and never again
     const int nt_rows = nt_env && nsuper == 1 && row_limit >= m->cap && row_begin * 2 <= m->cap;
     vm_prof_scope prof(m->ctx, VM_PROF_TOPK_SCAN, st);
@@ -557,14 +553,10 @@ int launch_emit(vm_memory *m, const void *queries, int Q, const float *thr_s, co
 template <int DT, int KS>
 int launch_emit_ng(vm_memory *m, const void *queries, int Q, const float *thr_s, const int *thr_o, int *cand_cnt,
                    float *cand_s, int *cand_o, int64_t row_begin, int64_t row_limit, hipStream_t st) {
-    static int deep_env = -1;
-    if (deep_env < 0) {
-        const char *e = getenv("VIDMEM_EMIT_DEEP");
-        // bit 0: one group per wave (<= 128 queries), bit 1: two groups per wave.  Measured on 1 M x 768 (A/B on one box):
-        // 256 queries 0.547 -> 0.528 ms with the deep schedule, 64 queries 0.312 -> 0.327 ms (a bandwidth-bound scan is not
-        // short of bytes in flight; the second barrier only costs)
-        deep_env = e ? atoi(e) : 2;
-    }
+    // bit 0: one group per wave (<= 128 queries), bit 1: two groups per wave.  Measured on 1 M x 768 (A/B on one box):
+    // 256 queries 0.547 -> 0.528 ms with the deep schedule, 64 queries 0.312 -> 0.327 ms (a bandwidth-bound scan is not
+    // short of bytes in flight; the second barrier only costs)
+    static const int deep_env = (int)VM_DEV_ENV("EMIT_DEEP", 2);
     if constexpr (KS <= 6) {  // two query groups per wave need 2 x 16 KS registers for the queries alone (192 of 256 at
         if (Q > EM_QPB) {     // D = 768: checked spill-free with -Rpass-analysis=kernel-resource-usage)
             if (deep_env & 2)
@@ -580,11 +572,7 @@ int launch_emit_ng(vm_memory *m, const void *queries, int Q, const float *thr_s,
 }  // namespace
 
 bool vm_topk_emit_supported(const vm_memory *m, int Q, int KL) {
-    static int env = -1;
-    if (env < 0) {
-        const char *e = getenv("VIDMEM_TOPK_EMIT");
-        env = e ? atoi(e) : 1;
-    }
+    static const int env = (int)VM_DEV_ENV("TOPK_EMIT", 1);
     if (!env) return false;
     const int ks = m->D / 128;
     const bool d_ok = m->D % 128 == 0 && (ks == 1 || ks == 2 || ks == 4 || ks == 6 || ks == 8);

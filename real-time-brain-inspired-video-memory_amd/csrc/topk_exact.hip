@@ -73,15 +73,21 @@ __global__ void __launch_bounds__(256)
 }
 
 // One block per query: k rounds, each finds the best key strictly after the previous winner in
-// (score desc, index asc) order.  Stateless, so any n works.
+// (score desc, index asc) order.  Stateless, so any n works.  col_limit (may be null): query q sees only the first
+// min(n, col_limit[q]) columns (vm_topk_select: the rows that existed before the query's own chunk was appended).
 __global__ void __launch_bounds__(256)
     topk_select_kernel(const double *__restrict__ scores, int64_t n, int64_t stride, int k, int use_min,
                        double min_score, int score_mode, int64_t base, int64_t row_stride, int64_t row_offset,
-                       double *__restrict__ out_scores, int64_t *__restrict__ out_rows) {
+                       double *__restrict__ out_scores, int64_t *__restrict__ out_rows,
+                       const int64_t *__restrict__ col_limit) {
     __shared__ double ws[256];
     __shared__ int64_t wi[256];
     const int q = blockIdx.x, tid = threadIdx.x;
     const double *s = scores + (size_t)q * stride;
+    if (col_limit) {
+        const int64_t lim = col_limit[q];
+        n = lim < 0 ? 0 : (lim < n ? lim : n);
+    }
     double prev_s = INFINITY;
     int64_t prev_i = -1;
     for (int r = 0; r < k; ++r) {
@@ -406,7 +412,19 @@ extern "C" int vm_topk_cosine_exact(vm_memory *m, const void *queries, int Q, in
         VM_LAUNCH_CHECK(ctx);
     }
     topk_select_kernel<<<Q, 256, 0, st>>>(sc, n, n, k, use_min_score, min_score, score_mode, base, row_stride,
-                                          row_offset, out_scores, out_rows);
+                                          row_offset, out_scores, out_rows, nullptr);
+    VM_LAUNCH_CHECK(ctx);
+    return VM_OK;
+}
+
+extern "C" int vm_topk_select(vm_ctx *ctx, const double *scores, int Q, int64_t S, const int64_t *col_limit, int k,
+                              int64_t row_base, double *out_scores, int64_t *out_rows, void *stream) {
+    if (!ctx || !scores || !out_scores || !out_rows || Q <= 0 || S < 0 || k <= 0)
+        return vm_fail(ctx, VM_ERR_INVALID, "vm_topk_select: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    vm_prof_scope prof(ctx, VM_PROF_TOPK_EXACT, st);
+    topk_select_kernel<<<Q, 256, 0, st>>>(scores, S, S, k, 0, 0.0, VM_SCORE_RAW, row_base, 1, 0, out_scores, out_rows,
+                                          col_limit);
     VM_LAUNCH_CHECK(ctx);
     return VM_OK;
 }

@@ -417,13 +417,9 @@ __global__ void __launch_bounds__(512, 1) topk_gscan_kernel(GscanArgs g) {
 }  // namespace
 
 bool vm_topk_gscan_supported(const vm_memory *m, int Q, int64_t rows) {
-    static int min_q = -1;
-    if (min_q < 0) {
-        const char *e = getenv("VIDMEM_GSCAN_MINQ");
-        // from 129 queries on: up to 128 the emit scan's single superblock is HBM-bound and as fast; 160 / 384 queries
-        // over 1 M x 768 rows: 0.47 -> 0.44 ms / 0.92 -> 0.76 ms (the emit scan needs a second, half-empty superblock)
-        min_q = e ? atoi(e) : 129;
-    }
+    // from 129 queries on: up to 128 the emit scan's single superblock is HBM-bound and as fast; 160 / 384 queries
+    // over 1 M x 768 rows: 0.47 -> 0.44 ms / 0.92 -> 0.76 ms (the emit scan needs a second, half-empty superblock)
+    static const int min_q = (int)VM_DEV_ENV("GSCAN_MINQ", 129);
     if (min_q <= 0 || Q < min_q || rows < 16384) return false;
     // enough 256 x 256 tiles for every CU to walk a few (a persistent tile walk with fewer leaves CUs idle for most of
     // the launch: the emit scan's 32-row tiles spread such a range better)
@@ -474,11 +470,7 @@ int vm_topk_gscan(vm_memory *m, const void *queries, int Q, int q_thr, const flo
             best_qx = qx;
         }
     }
-    static int qx_env = -1;
-    if (qx_env < 0) {
-        const char *e = getenv("VIDMEM_GSCAN_QX");
-        qx_env = e ? atoi(e) : 0;
-    }
+    static const int qx_env = (int)VM_DEV_ENV("GSCAN_QX", 0);
     g.QX = (qx_env == 1 || qx_env == 2 || qx_env == 4 || qx_env == 8) ? qx_env : best_qx;
     auto kern = m->dtype == VM_F16 ? topk_gscan_kernel<VM_F16> : topk_gscan_kernel<VM_BF16>;
     static unsigned long long attr_set[2] = {0, 0};   // per dtype, one bit per device

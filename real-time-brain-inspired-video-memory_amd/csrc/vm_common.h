@@ -5,9 +5,24 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/vidmem.h"
+
+// Developer A/B switches.  The release library (make / __graft_entry__.build()) compiles every one of them to its
+// default: no environment variable selects which kernel produces product results, and no VIDMEM_* name appears in
+// libvidmem.so.  tools/dev_build.sh builds with -DVM_DEV_SWITCHES, where each is read from the environment once per
+// process.  What a deployment may choose is an explicit per-handle option (vm_encoder_set_option, include/vidmem.h).
+#ifdef VM_DEV_SWITCHES
+static inline long vm_dev_env_(const char *name, long dflt) {
+    const char *e = getenv(name);
+    return e ? atol(e) : dflt;
+}
+#define VM_DEV_ENV(name, dflt) vm_dev_env_("VIDMEM_" name, (dflt))
+#else
+#define VM_DEV_ENV(name, dflt) ((long)(dflt))
+#endif
 
 struct vm_ctx {
     int device;

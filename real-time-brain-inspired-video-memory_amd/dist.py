@@ -10,7 +10,10 @@ Exchange per search (the only collectives on the path, RCCL over xGMI; backend "
      cannot certify are redone exhaustively on the device, csrc/topk_exact.hip, so every shard's list is exact)
   3. all-gather of the candidates {fp64 score, int64 global row} [world*F, k]
   4. merge of the `world` candidate lists of this rank's own queries        (csrc/topk.hip topk_merge_kernel)
-No bulk row traffic ever crosses GPUs.  With world == 1 there is no collective and no torch.distributed import.
+No bulk row traffic ever crosses GPUs.  With world == 1 there is no collective and no torch.distributed import -
+unless ``force_collectives`` asks for them: a one-rank group still runs both all-gathers through the backend (RCCL
+loads, gathers fp16 / fp64 / int64 device tensors, and the stream ordering around ``vm_topk_merge`` is the N > 1 one),
+which is how a one-GPU box exercises the ``nccl`` branch (tests/test_dist_gpu.py, tools/rccl_world1.py).
 """
 from __future__ import annotations
 
@@ -21,12 +24,14 @@ import torch
 
 class ShardedRetriever:
     def __init__(self, memory, rank: int = 0, world: int = 1, group=None,
-                 local_topk: Optional[Callable] = None, merge: Optional[Callable] = None):
+                 local_topk: Optional[Callable] = None, merge: Optional[Callable] = None,
+                 force_collectives: bool = False):
         """``local_topk(queries, k, row_stride, row_offset) -> (scores, rows)`` and
         ``merge(scores[parts,Q,k], rows[parts,Q,k]) -> (scores[Q,k], rows[Q,k])`` default to the HIP kernels;
         the CPU gloo tests inject checkers to exercise the sharding logic without a GPU."""
         self.memory = memory
         self.rank, self.world, self.group = int(rank), int(world), group
+        self.force_collectives = bool(force_collectives)
         if local_topk is None:
             def local_topk(q, k, stride, offset):
                 # exhaustive answer on the local shard: the scan's uncertified queries are redone on the device
@@ -41,7 +46,7 @@ class ShardedRetriever:
 
     def search(self, queries: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
         """queries [F, D] (this rank's) -> global top-k (scores [F,k] fp64, global rows [F,k] int64)."""
-        if self.world == 1:
+        if self.world == 1 and not self.force_collectives:
             return self._local_topk(queries, k, 1, 0)
         F = queries.shape[0]
         q_all = self._all_gather(queries)                                   # [world*F, D], rank-major

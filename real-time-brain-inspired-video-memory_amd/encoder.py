@@ -32,7 +32,10 @@ _MATRICES = ("patch_w", "proj_w", "qkv_w", "fc1_w", "fc2_w")
 class FrameEncoder:
     """uint8 BGR frames -> L2-normalised 16-bit embeddings, everything on the device."""
 
-    def __init__(self, spec: Dict, weights: Dict[str, np.ndarray], dtype: str = "f16", device: int = 0):
+    def __init__(self, spec: Dict, weights: Dict[str, np.ndarray], dtype: str = "f16", device: int = 0,
+                 schedule: str = "auto", micro_batch: int = 0, last_layer: int = 3):
+        """schedule / micro_batch / last_layer: include/vidmem.h vm_encoder_set_option (same embeddings for every
+        value; "auto" runs calls of two or more passes on two internal streams)."""
         self.spec = dict(spec)
         self.ctx = _lib.Context.get(device)
         self.L = self.ctx.L
@@ -71,9 +74,28 @@ class FrameEncoder:
         self.tokens = int(self.L.vm_encoder_tokens(h))
         self.out_dim = int(self.L.vm_encoder_out_dim(h))
         assert int(self.L.vm_encoder_patch_k(h)) == self.patch_k
+        self.set_schedule(schedule)
+        if micro_batch:
+            self.set_option(_lib.VM_ENC_OPT_MICRO_BATCH, int(micro_batch))
+        if last_layer != 3:
+            self.set_option(_lib.VM_ENC_OPT_LAST_LAYER, int(last_layer))
         self._ws = None
         self._mean = (C.c_float * 3)(*spec["mean"])
         self._std = (C.c_float * 3)(*spec["std"])
+
+    def set_option(self, option: int, value: int) -> None:
+        self.ctx.check(self.L.vm_encoder_set_option(self.handle, int(option), int(value)))
+
+    def set_schedule(self, schedule: str) -> None:
+        """"auto" | "one_stream" | "two_streams" (vm_encoder_schedule)."""
+        if schedule not in _lib.SCHEDULES:
+            raise ValueError(f"schedule must be one of {sorted(_lib.SCHEDULES)}")
+        self.set_option(_lib.VM_ENC_OPT_SCHEDULE, _lib.SCHEDULES[schedule])
+
+    @property
+    def schedule(self) -> str:
+        v = int(self.L.vm_encoder_get_option(self.handle, _lib.VM_ENC_OPT_SCHEDULE))
+        return {n: k for k, n in _lib.SCHEDULES.items()}[v]
 
     def close(self):
         if getattr(self, "handle", None):

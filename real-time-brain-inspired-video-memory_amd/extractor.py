@@ -160,7 +160,9 @@ class FrameEmbeddingExtractor:
 
     def _stage(self, frames: List[np.ndarray], group_chunks: int = 1):
         """Start the H2D copy of a group of chunks (ingest.FrameStager: pinned slot + copy stream); the stager is sized
-        on the first group and rebuilt if the frame size changes."""
+        on the first group and rebuilt if the frame size changes.  Returns (stager, ticket): a ticket is redeemed at the
+        stager that issued it, which the consumer therefore gets with it - ``self._stager`` may already be a newer one
+        (this runs on the staging thread, ahead of the consumer)."""
         h, w = frames[0].shape[:2]
         fpc = int(cfgmod.section(self.config, "video", cfgmod.VIDEO_DEFAULTS).frames_per_chunk)
         cap = max(len(frames), fpc * max(1, group_chunks))
@@ -168,8 +170,17 @@ class FrameEmbeddingExtractor:
             factory = self._stager_factory
             if factory is None:
                 from .ingest import FrameStager as factory
+            old = self._stager
             self._stager = factory(cap, h, w, self.encoder.device.index or 0)
-        return self._stager.stage(frames)
+            if old is not None and hasattr(old, "close_pool"):
+                old.close_pool()   # its copy threads; its slots live as long as a ticket in flight still refers to it
+        return self._stager, self._stager.stage(frames)
+
+    def close(self) -> None:
+        """Release the staging slots (pinned host + device) and their copy threads."""
+        if self._stager is not None and hasattr(self._stager, "close"):
+            self._stager.close()
+        self._stager = None
 
     def _auto_look_ahead(self, src, frames_per_chunk: int, slot_bytes: int = 256 << 20) -> int:
         """``look_ahead_chunks: 0``: as many chunks per group as fill one encoder pass (FrameEncoder.micro_batch: 883
@@ -192,8 +203,10 @@ class FrameEmbeddingExtractor:
               arithmetic on the same 16-bit values the memory's re-scoring uses), masked to "chunks before mine", k best by
               (score descending, row ascending) - a stable sort over append order, row id = the id the row is about to get;
           (3) ``vm_topk_merge`` of the two lists (the kernel that merges per-shard lists: same order relation).
-        Only called when no stored row can be overwritten while the group is appended (see the caller)."""
-        from .memory import topk_merge
+        Only called when no stored row can be overwritten while the group is appended (see the caller).
+        The (score descending, row ascending) rule lives in the library alone: ``vm_topk_select`` ranks every frame
+        against the columns before its own chunk, ``vm_topk_merge`` folds the two lists."""
+        from .memory import topk_merge, topk_select
         F, k = emb_all.shape[0], self.top_k
         dev = emb_all.device
         base = len(self.memory)                                   # id of the group's first row
@@ -202,25 +215,19 @@ class FrameEmbeddingExtractor:
         else:
             s_mem = torch.zeros((F, k), dtype=torch.float64, device=dev)
             r_mem = torch.full((F, k), -1, dtype=torch.int64, device=dev)
-        col = torch.arange(F, device=dev)
         if all(c == counts[0] for c in counts):
             # equal chunks (every group but a clip's ragged last one): the first row of each frame's chunk is computed
             # on the device.  A host list would have to be COPIED in stream order, i.e. the host would sit behind the
             # encoder launches it has just queued, and the GPU would idle afterwards while the host catches up
-            starts = col // counts[0] * counts[0]
+            starts = torch.arange(F, device=dev) // counts[0] * counts[0]
         else:
-            starts = torch.repeat_interleave(torch.tensor([sum(counts[:i]) for i in range(len(counts))], device=dev),
-                                             torch.tensor(counts, device=dev))
-        g = self.memory.cosine_exact(emb_all, emb_all)            # [F, F] fp64
-        g = g.masked_fill(col[None, :] >= starts[:, None], float("-inf"))
-        kk = min(k, F)
-        vals, idx = torch.sort(g, dim=1, descending=True, stable=True)
-        vals, idx = vals[:, :kk], idx[:, :kk]
-        valid = vals > float("-inf")
-        s_grp = torch.zeros((F, k), dtype=torch.float64, device=dev)
-        r_grp = torch.full((F, k), -1, dtype=torch.int64, device=dev)
-        s_grp[:, :kk] = torch.where(valid, vals, torch.zeros_like(vals))
-        r_grp[:, :kk] = torch.where(valid, idx + base, torch.full_like(idx, -1))
+            first, starts_h = 0, []
+            for c in counts:
+                starts_h += [first] * c
+                first += c
+            starts = torch.tensor(starts_h, dtype=torch.int64, device=dev)
+        g = self.memory.cosine_exact(emb_all, emb_all)            # [F, F] fp64, the reference's arithmetic
+        s_grp, r_grp = topk_select(self.memory.ctx, g, k, col_limit=starts, row_base=base)
         return topk_merge(self.memory.ctx, torch.stack([s_mem, s_grp]), torch.stack([r_mem, r_grp]))
 
     async def process_video(self, video_path: str, output_path: str) -> str:
@@ -265,19 +272,27 @@ class FrameEmbeddingExtractor:
                         ok = [i for i in indices if 0 <= i < src.total]      # an unreadable frame is dropped (:111)
                         counts.append(len(ok))
                         picks += ok
-                    return counts, (self._stage(read_many(picks), L) if picks else None)
+                    return counts, (self._stage(read_many(picks), L) if picks else (None, None))
                 for (_ci, _s, _e, indices, _t) in groups[gi]:
                     fr = self._read_chunk(src, indices)
                     counts.append(len(fr))
                     frames += fr
-                return counts, (self._stage(frames, L) if frames else None)
+                return counts, (self._stage(frames, L) if frames else (None, None))
 
             def finish(pend):
-                """Read one group's neighbours back (its event has fired long before the host gets here)."""
-                chunks, host_s, host_r, ev, t_start = pend
+                """Read one group's neighbours back (its event has fired long before the host gets here).
+                ``processing_time`` (:62-71 times ONE chunk around its own work): the group's own DEVICE time - from
+                the first kernel of its encoder call to its last append, a pair of events on the launch stream, so
+                neither the host work queued for the next group nor the frame reads on the staging thread are in it -
+                divided by the chunks of the group; ``group_time`` / ``group_chunks`` carry the undivided figure.
+                With one chunk per group (the config default of the reference's loop) it is that chunk's device time.
+                A host stand-in for the encoder (CPU tests) has no events: wall time since the group was taken up."""
+                chunks, host_s, host_r, ev0, ev, t_start = pend
                 if ev is not None:
                     ev.synchronize()
-                group_time = time.perf_counter() - t_start
+                    group_time = ev0.elapsed_time(ev) * 1e-3
+                else:
+                    group_time = time.perf_counter() - t_start
                 live = [c for c in chunks if c["nframes"]]
                 off = 0
                 for c in live:
@@ -293,6 +308,8 @@ class FrameEmbeddingExtractor:
                         "content": f"[{c['nframes']} frame embeddings]",
                         "chunk_idx": c["chunk_idx"],
                         "processing_time": chunk_time,
+                        "group_time": group_time,
+                        "group_chunks": len(live),
                         "embedding_rows": list(range(c["first"], c["first"] + c["nframes"])),
                         "similar": similar,
                     })
@@ -311,83 +328,102 @@ class FrameEmbeddingExtractor:
             depth = 2
             credits = threading.Semaphore(depth)
             staged_q: "queue.Queue" = queue.Queue()
+            stop = threading.Event()
 
             def stage_all():
                 try:
                     for gi in range(len(groups)):
                         credits.acquire()
+                        if stop.is_set():      # the consumer gave up (an exception in the main loop): touch nothing more
+                            return
                         staged_q.put(read_and_stage(gi))
                 except BaseException as exc:   # surfaces in the main loop
                     staged_q.put(exc)
 
             stager_thread = threading.Thread(target=stage_all, name="vidmem-stage", daemon=True)
             stager_thread.start()
-            pending = None
-            for gi, grp in enumerate(groups):
-                t_start = time.perf_counter()
-                staged = staged_q.get()
-                if isinstance(staged, BaseException):
-                    raise staged
-                counts, ticket = staged
-                emb_all = None
-                if ticket is not None:
-                    emb_all = self.encoder.embed_frames(self._stager.get(ticket))   # asynchronous launches
-                    self._stager.done(ticket)
-                credits.release()
-                chunks, dev_s, dev_r, off = [], [], [], 0
-                total = sum(counts)
-                # One search for the whole group when that is provably the same thing: every chunk of the group still
-                # sees exactly "the memory before the group + the group's earlier chunks", i.e. no row of the memory is
-                # overwritten while the group is appended (not a ring, or a ring that does not wrap inside the group).
-                batched = (len(grp) > 1 and emb_all is not None and self.top_k > 0 and emb_all.is_cuda and
-                           (not self.memory.ring or len(self.memory) + total <= self.memory.capacity))
-                if batched:
-                    grp_s, grp_r = self._group_search(emb_all, counts)
-                for (chunk_idx, start, end, indices, time_str), nframes in zip(grp, counts):
-                    c = {"chunk_idx": chunk_idx, "time": time_str, "nframes": nframes, "searched": False, "first": 0}
-                    chunks.append(c)
-                    if not nframes:
-                        continue
-                    emb = emb_all[off:off + nframes]
+            try:
+                pending = None
+                for gi, grp in enumerate(groups):
+                    t_start = time.perf_counter()
+                    staged = staged_q.get()
+                    if isinstance(staged, BaseException):
+                        raise staged
+                    counts, (stager, ticket) = staged
+                    emb_all = ev0 = None
+                    if ticket is not None:
+                        frames_dev = stager.get(ticket)
+                        if getattr(frames_dev, "is_cuda", False):
+                            ev0 = torch.cuda.Event(enable_timing=True)
+                            ev0.record(torch.cuda.current_stream(dev))
+                        emb_all = self.encoder.embed_frames(frames_dev)   # asynchronous launches
+                        stager.done(ticket)
+                    credits.release()
+                    chunks, dev_s, dev_r, off = [], [], [], 0
+                    total = sum(counts)
+                    # One search for the whole group when that is provably the same thing: every chunk of the group still
+                    # sees exactly "the memory before the group + the group's earlier chunks", i.e. no row of the memory is
+                    # overwritten while the group is appended (not a ring, or a ring that does not wrap inside the group).
+                    batched = (len(grp) > 1 and emb_all is not None and self.top_k > 0 and emb_all.is_cuda and
+                               (not self.memory.ring or len(self.memory) + total <= self.memory.capacity))
                     if batched:
-                        if self.memory.searchable + off > 0:       # what `memory.searchable` will be when chunk i's turn comes
-                            dev_s.append(grp_s[off:off + nframes])
-                            dev_r.append(grp_r[off:off + nframes])
+                        grp_s, grp_r = self._group_search(emb_all, counts)
+                    for (chunk_idx, start, end, indices, time_str), nframes in zip(grp, counts):
+                        c = {"chunk_idx": chunk_idx, "time": time_str, "nframes": nframes, "searched": False, "first": 0}
+                        chunks.append(c)
+                        if not nframes:
+                            continue
+                        emb = emb_all[off:off + nframes]
+                        if batched:
+                            if self.memory.searchable + off > 0:       # what `memory.searchable` will be when chunk i's turn comes
+                                dev_s.append(grp_s[off:off + nframes])
+                                dev_r.append(grp_r[off:off + nframes])
+                                c["searched"] = True
+                        elif self.memory.searchable and self.top_k > 0:
+                            scores, rows = self.memory.topk(emb, self.top_k)
+                            dev_s.append(scores)
+                            dev_r.append(rows)
                             c["searched"] = True
-                    elif self.memory.searchable and self.top_k > 0:
-                        scores, rows = self.memory.topk(emb, self.top_k)
-                        dev_s.append(scores)
-                        dev_r.append(rows)
-                        c["searched"] = True
-                    off += nframes
-                    ids = [f"{run_id}_{chunk_idx}_{i}" for i in range(nframes)]  # pre_llm_injector.py:91 id scheme
-                    created = time.strftime("%Y-%m-%dT%H:%M:%S+00:00", time.gmtime())   # Chunk.created_at of the export
-                    c["ids"] = ids
-                    c["meta"] = [{"time": time_str, "content": None, "batch_id": chunk_idx, "created_at": created}] * nframes
-                    if not batched:
-                        c["first"] = self.memory.append(emb, ids=ids, meta=c["meta"])
-                if batched:      # one append for the group: rows, ids and meta in chunk order
-                    live = [c for c in chunks if c["nframes"]]
-                    first = self.memory.append(emb_all, ids=[i for c in live for i in c["ids"]],
-                                               meta=[m for c in live for m in c["meta"]])
-                    for c in live:
-                        c["first"] = first
-                        first += c["nframes"]
-                host_s = host_r = ev = None
-                if dev_s:
-                    cat_s, cat_r = torch.cat(dev_s), torch.cat(dev_r)
-                    host_s = torch.empty(cat_s.shape, dtype=cat_s.dtype).pin_memory()
-                    host_r = torch.empty(cat_r.shape, dtype=cat_r.dtype).pin_memory()
-                    host_s.copy_(cat_s, non_blocking=True)
-                    host_r.copy_(cat_r, non_blocking=True)
-                if emb_all is not None and emb_all.is_cuda:   # (a host stand-in for the encoder in the CPU tests: no event)
-                    ev = torch.cuda.Event()
-                    ev.record(torch.cuda.current_stream(dev))
+                        off += nframes
+                        ids = [f"{run_id}_{chunk_idx}_{i}" for i in range(nframes)]  # pre_llm_injector.py:91 id scheme
+                        created = time.strftime("%Y-%m-%dT%H:%M:%S+00:00", time.gmtime())   # Chunk.created_at of the export
+                        c["ids"] = ids
+                        c["meta"] = [{"time": time_str, "content": None, "batch_id": chunk_idx, "created_at": created}] * nframes
+                        if not batched:
+                            c["first"] = self.memory.append(emb, ids=ids, meta=c["meta"])
+                    if batched:      # one append for the group: rows, ids and meta in chunk order
+                        live = [c for c in chunks if c["nframes"]]
+                        first = self.memory.append(emb_all, ids=[i for c in live for i in c["ids"]],
+                                                   meta=[m for c in live for m in c["meta"]])
+                        for c in live:
+                            c["first"] = first
+                            first += c["nframes"]
+                    host_s = host_r = ev = None
+                    if dev_s:
+                        cat_s, cat_r = torch.cat(dev_s), torch.cat(dev_r)
+                        host_s = torch.empty(cat_s.shape, dtype=cat_s.dtype).pin_memory()
+                        host_r = torch.empty(cat_r.shape, dtype=cat_r.dtype).pin_memory()
+                        host_s.copy_(cat_s, non_blocking=True)
+                        host_r.copy_(cat_r, non_blocking=True)
+                    if ev0 is not None:   # (a host stand-in for the encoder in the CPU tests: no event)
+                        ev = torch.cuda.Event(enable_timing=True)
+                        ev.record(torch.cuda.current_stream(dev))
+                    if pending is not None:
+                        finish(pending)
+                    pending = (chunks, host_s, host_r, ev0, ev, t_start)
                 if pending is not None:
                     finish(pending)
-                pending = (chunks, host_s, host_r, ev, t_start)
-            if pending is not None:
-                finish(pending)
+            finally:
+                # the staging thread is the only one that touches ``src`` and the pinned slots: it is stopped and JOINED
+                # before ``src.release()`` below runs, whatever ended the loop (a full non-ring memory, an encoder or
+                # top-k error, a failing consumer).  It is either inside read_and_stage - which returns - or waiting for
+                # a credit, which it now gets and then sees ``stop``.
+                stop.set()
+                for _ in range(depth):
+                    credits.release()
+                stager_thread.join()
+                if self._stager is not None and hasattr(self._stager, "close_pool"):
+                    self._stager.close_pool()     # the slab-copy workers; the slots stay for the next clip
             output_data = {
                 "metadata": {"run_id": run_id, "video_path": video_path, "total_chunks": total_chunks,
                              "config": cfgmod.config_dict(self.config)},

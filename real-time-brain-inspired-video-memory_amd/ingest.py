@@ -109,6 +109,18 @@ class FrameStager:
             hv[i] = f
         return self.commit(n)
 
+    def close_pool(self) -> None:
+        """Stop the slab-copy worker threads (they are started again by the next ``stage`` that needs them)."""
+        if self._pool is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None
+
+    def close(self) -> None:
+        """Stop the worker threads and drop the slots (pinned host and device memory go back to their allocators once
+        the last ticket's tensors are gone)."""
+        self.close_pool()
+        self.host, self.dev = [], []
+
     def get(self, ticket: Ticket) -> torch.Tensor:
         """Device view [n,H,W,3] of a staged chunk; the CURRENT stream waits for the copy (the host does not)."""
         if self._seq - ticket.seq > self.depth:

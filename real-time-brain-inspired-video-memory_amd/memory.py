@@ -302,6 +302,26 @@ class TopkScratch:
         return cls(memory.device, Q, k, ws, redo)
 
 
+def topk_select(ctx: "_lib.Context", scores: torch.Tensor, k: int, col_limit: Optional[torch.Tensor] = None,
+                row_base: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+    """[Q,S] fp64 all-pairs scores -> the k best columns of every row by (score descending, column ascending), query q
+    ranking only columns < col_limit[q] (vm_topk_select; csrc/topk_exact.hip).  Rows = row_base + column, -1 padded."""
+    Q, S = scores.shape
+    scores = scores.contiguous()
+    lim = None
+    if col_limit is not None:
+        lim = col_limit.to(device=scores.device, dtype=torch.int64).contiguous()
+        if lim.shape != (Q,):
+            raise ValueError("col_limit must hold one limit per query")
+    out_s = torch.empty((Q, k), dtype=torch.float64, device=scores.device)
+    out_r = torch.empty((Q, k), dtype=torch.int64, device=scores.device)
+    ctx.check(ctx.L.vm_topk_select(ctx.handle, C.c_void_p(scores.data_ptr()), Q, S,
+                                   C.c_void_p(lim.data_ptr() if lim is not None else 0), int(k), int(row_base),
+                                   C.c_void_p(out_s.data_ptr()), C.c_void_p(out_r.data_ptr()),
+                                   _lib.current_stream_ptr()))
+    return out_s, out_r
+
+
 def topk_merge(ctx: "_lib.Context", scores: torch.Tensor, rows: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """[parts,Q,k] per-shard results -> global [Q,k] (csrc/topk.hip topk_merge_kernel)."""
     parts, Q, k = scores.shape

@@ -46,6 +46,16 @@ def test_gfx950_code_object_is_embedded(built):
     assert b"gfx950" in data and b"gfx942" not in data and b"sm_" not in data
 
 
+def test_release_library_reads_no_environment(built):
+    """The developer A/B switches (csrc/vm_common.h VM_DEV_ENV) are compiled to their defaults in the release library: no
+    VIDMEM_* name and no getenv import may be left in it - a stray variable in a deployment's environment must not be
+    able to change which kernel produces product results."""
+    data = open(built.LIB_PATH, "rb").read()
+    assert b"VIDMEM_" not in data
+    und = subprocess.check_output(["nm", "-D", "--undefined-only", built.LIB_PATH], text=True)
+    assert "getenv" not in und
+
+
 def test_no_gpu_means_loud_failure(built):
     import torch
     if torch.cuda.is_available():
@@ -55,7 +65,7 @@ def test_no_gpu_means_loud_failure(built):
     assert e.value.code == built.VM_ERR_NO_DEVICE
     h = ctypes.c_void_p()
     assert built.lib().vm_init(0, ctypes.byref(h)) == built.VM_ERR_NO_DEVICE
-    assert built.lib().vm_abi_version() == 3
+    assert built.lib().vm_abi_version() == 4
 
 
 def test_product_package_never_imports_the_oracle():

@@ -27,8 +27,13 @@ TD = {"f16": torch.float16, "bf16": torch.bfloat16}
 #         the SAME stack is evaluated in the test), and the device stores everything that is not a matrix operand in
 #         fp16 (csrc/vm_kernels.h EPI_DELTA16).  Against the quant-aware oracle the bar is the same: one flipped bf16
 #         rounding is 2^-8 of an element, so that comparison is as noisy as the fp32 one.
+#         That is a STATED DEVIATION from BASELINE.json's 1e-3: bf16 embedding parity is unpinned by the
+#         reference (it holds no encoder) and is NOT "within 1e-3".  Against the quant-aware golden - the same rounding
+#         points, so only accumulation order and flipped roundings remain - the full models are held to the tighter
+#         QUANT_SLACK x floor (measured 0.93 x batch, 0.97-1.01 x worst frame).
 CONTRACT = 1e-3
 FLOOR_SLACK = 1.5
+QUANT_SLACK = 1.15
 _FLOOR_JSON = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bf16_floor_clip_l14_336_bf16.json")
 
 
@@ -53,9 +58,9 @@ def rel(a, b):
     return float(np.linalg.norm(a - b) / np.linalg.norm(b))
 
 
-def _encoder(spec, w, dtype):
+def _encoder(spec, w, dtype, **options):
     from vidmem.encoder import FrameEncoder
-    return FrameEncoder(spec, w, dtype=dtype)
+    return FrameEncoder(spec, w, dtype=dtype, **options)
 
 
 @pytest.fixture(scope="module")
@@ -178,7 +183,11 @@ def test_full_models_match_golden(name, dtype, golden):
           f"{floor[1:][per32.argmax()]:.2e}, bar {frame_bar[per32.argmax()]:.2e}), vs quant-aware worst {perq.max():.2e}")
     assert e_q < bar and e_32 < bar
     assert (per32 < frame_bar).all(), (per32, frame_bar)
-    assert (perq < frame_bar).all(), (perq, frame_bar)
+    if dtype == "f16":
+        assert (perq < frame_bar).all(), (perq, frame_bar)
+    else:   # same rounding points on both sides: the tighter bar (a real kernel error moves this first)
+        assert e_q < max(CONTRACT, QUANT_SLACK * float(floor[0])), (e_q, floor[0])
+        assert (perq < np.maximum(CONTRACT, QUANT_SLACK * floor[1:])).all(), (perq, floor[1:])
     # the same per frame as an angle: for unit vectors 1 - cos = e^2 / 2 (directions compared in fp64; the 16-bit
     # output's own norm is 1 only to an ulp)
     cos = (g64 * f64).sum(1) / (np.linalg.norm(g64, axis=1) * np.linalg.norm(f64, axis=1))
@@ -202,16 +211,20 @@ def test_bf16_encoder_survives_activations_beyond_fp16_range():
     got = enc.encode_patches(enc.patches_from_pixels(torch.from_numpy(px))).float().cpu().numpy()
     assert np.isfinite(got).all()
     assert np.allclose(np.linalg.norm(got, axis=1), 1.0, atol=8e-3)
+    # ... and a NaN must stay visible: the saturating store keeps it (csrc/gemm.hip sat_f16), so a broken activation
+    # cannot hide behind a finite, wrong embedding
+    w["l0.fc2_b"][8] = np.float32("nan")
+    bad = _encoder(spec, w, "bf16")
+    got = bad.encode_patches(bad.patches_from_pixels(torch.from_numpy(px))).float().cpu().numpy()
+    assert np.isnan(got).all()
 
 
-def test_batching_is_invisible(monkeypatch):
+def test_batching_is_invisible():
     """Frame i's embedding must not depend on what else is in the launch or where micro-batches split."""
     from vidmem import synthetic as syn, specs
     spec = dict(specs.VIT_B16_224, layers=2)
     w = syn.encoder_weights(spec, seed=9)
-    monkeypatch.setenv("VIDMEM_MICROBATCH", "64")     # read at encoder creation: 150 frames = passes of 64, 64, 22
-    enc = _encoder(spec, w, "f16")
-    monkeypatch.delenv("VIDMEM_MICROBATCH")
+    enc = _encoder(spec, w, "f16", micro_batch=64)     # 150 frames = passes of 64, 64, 22 (two streams: the default)
     frames = torch.from_numpy(syn.frames_u8(99, 150, 224, 224)).cuda()
     all_emb = enc.embed_frames(frames)
     head = enc.embed_frames(frames[:3])
@@ -221,9 +234,9 @@ def test_batching_is_invisible(monkeypatch):
 
 
 @pytest.mark.parametrize("dtype,image,patch,hidden,heads,n", [("f16", 224, 16, 768, 12, 130), ("bf16", 336, 14, 1024, 16, 40)])
-def test_last_layer_on_cls_rows_is_invisible(monkeypatch, dtype, image, patch, hidden, heads, n):
+def test_last_layer_on_cls_rows_is_invisible(dtype, image, patch, hidden, heads, n):
     """vm_encode runs the LAST layer's query projection, attention query tile, attention projection, LN2 and MLP on the
-    CLS rows only (the one row the embedding is pooled from).  Against an encoder created with VIDMEM_CLS_LAST=0
+    CLS rows only (the one row the embedding is pooled from).  Against an encoder with VM_ENC_OPT_LAST_LAYER = 0
     (everything on every row) the embeddings must be identical BIT FOR BIT, for both attention kernels (197 / 577
     tokens) and for batches that take the persistent 256 x 256 GEMM (n x tokens rows) as well as 3-frame ones."""
     from vidmem import synthetic as syn, specs
@@ -232,11 +245,8 @@ def test_last_layer_on_cls_rows_is_invisible(monkeypatch, dtype, image, patch, h
     assert (spec["image"], spec["patch"], spec["hidden"], spec["heads"]) == (image, patch, hidden, heads)
     w = syn.encoder_weights(spec, seed=31)
     frames = torch.from_numpy(syn.frames_u8(77, n, image, image)).cuda()
-    monkeypatch.setenv("VIDMEM_CLS_LAST", "0")           # read when the encoder is created
-    full = _encoder(spec, w, dtype)
-    monkeypatch.setenv("VIDMEM_CLS_LAST", "1")           # projection + MLP pruned, attention on every row
-    half = _encoder(spec, w, dtype)
-    monkeypatch.delenv("VIDMEM_CLS_LAST")
+    full = _encoder(spec, w, dtype, last_layer=0)
+    half = _encoder(spec, w, dtype, last_layer=1)        # projection + MLP pruned, attention on every row
     pruned = _encoder(spec, w, dtype)
     want = full.embed_frames(frames)
     assert torch.isfinite(want.float()).all()
@@ -245,37 +255,43 @@ def test_last_layer_on_cls_rows_is_invisible(monkeypatch, dtype, image, patch, h
     assert torch.equal(pruned.embed_frames(frames[:3]), want[:3])
     one = dict(spec, layers=1)                           # the last layer is also the first: no pending branch outputs
     w1 = syn.encoder_weights(one, seed=32)
-    monkeypatch.setenv("VIDMEM_CLS_LAST", "0")
-    full1 = _encoder(one, w1, dtype)
-    monkeypatch.delenv("VIDMEM_CLS_LAST")
+    full1 = _encoder(one, w1, dtype, last_layer=0)
     assert torch.equal(_encoder(one, w1, dtype).embed_frames(frames[:5]), full1.embed_frames(frames[:5]))
 
 
 @pytest.mark.parametrize("name,dtype,mbatch,n", [("vit_b16_224", "f16", 64, 200), ("clip_l14_336", "bf16", 28, 70)])
-def test_two_stream_mode_is_invisible(monkeypatch, name, dtype, mbatch, n):
-    """VIDMEM_ENC_DUAL=1 (read when the encoder is created): consecutive micro-batch passes of a call alternate between
-    two internal streams with a workspace each, and the LayerNorms run their low-register build.  Embeddings must equal
-    the single-stream encoder's bit for bit - an even and an odd number of passes, a ragged last pass, and calls of one
-    pass (where the mode does nothing) in between."""
+def test_two_stream_mode_is_invisible(name, dtype, mbatch, n):
+    """The DEFAULT schedule (VM_SCHED_AUTO): consecutive micro-batch passes of a call alternate between two internal
+    streams with a workspace each, and the LayerNorms run their low-register build.  Embeddings must equal the
+    one-stream encoder's bit for bit - an even and an odd number of passes, a ragged last pass, and calls of one
+    pass (where the schedule does nothing) in between; also with the schedule forced, and with per-kernel timing on
+    (where AUTO falls back to one stream)."""
     from vidmem import synthetic as syn
     spec = dict(V.SPECS[name], layers=3)
     w = syn.encoder_weights(spec, seed=17)
-    monkeypatch.setenv("VIDMEM_MICROBATCH", str(mbatch))
-    plain = _encoder(spec, w, dtype)
-    monkeypatch.setenv("VIDMEM_ENC_DUAL", "1")
-    dual = _encoder(spec, w, dtype)
-    monkeypatch.delenv("VIDMEM_ENC_DUAL")
-    monkeypatch.delenv("VIDMEM_MICROBATCH")
+    plain = _encoder(spec, w, dtype, micro_batch=mbatch, schedule="one_stream")
+    dual = _encoder(spec, w, dtype, micro_batch=mbatch)       # the default path
+    forced = _encoder(spec, w, dtype, micro_batch=mbatch, schedule="two_streams")
+    assert dual.schedule == "auto" and plain.schedule == "one_stream" and forced.schedule == "two_streams"
     assert dual.workspace_bytes(n) == 2 * plain.workspace_bytes(n) and dual.workspace_bytes(3) == plain.workspace_bytes(3)
     S = spec["image"]
     frames = torch.from_numpy(syn.frames_u8(5, n, S, S)).cuda()
     for count in (n, 2 * mbatch, 3, 3 * mbatch - 5):          # 4 passes (ragged) / 2 / 1 / 3 (ragged)
         want = plain.embed_frames(frames[:count])
-        got = dual.embed_frames(frames[:count])
         assert torch.isfinite(want.float()).all()
-        if not torch.equal(got, want):    # say where: which rows (frames) differ tells which pass / stream
-            rows = ((got.float() - want.float()).abs().amax(dim=1) > 0).nonzero().flatten().tolist()
-            raise AssertionError(f"{count} frames: {len(rows)} embeddings differ, first rows {rows[:10]}")
+        for label, enc in (("auto", dual), ("two_streams", forced)):
+            got = enc.embed_frames(frames[:count])
+            if not torch.equal(got, want):    # say where: which rows (frames) differ tells which pass / stream
+                rows = ((got.float() - want.float()).abs().amax(dim=1) > 0).nonzero().flatten().tolist()
+                raise AssertionError(f"{label}, {count} frames: {len(rows)} embeddings differ, first rows {rows[:10]}")
+    # per-kernel timing on: AUTO runs one stream (clean event durations), TWO_STREAMS stays on two; same bits
+    dual.ctx.profile_enable(4096)
+    try:
+        assert torch.equal(dual.embed_frames(frames), plain.embed_frames(frames))
+        assert torch.equal(forced.embed_frames(frames), plain.embed_frames(frames))
+        assert dual.ctx.profile_read()["layernorm"][1] > 0
+    finally:
+        dual.ctx.profile_enable(0)
 
 
 @pytest.mark.parametrize("name,dtype,n", [("vit_b16_224", "f16", 1000), ("clip_l14_336", "bf16", 260)])
@@ -314,17 +330,23 @@ def test_bench_size_batches_take_the_big_kernels_and_agree(name, dtype, n):
 
 
 def test_long_attention_variants_agree(tmp_path):
-    """The 577-token attention has three builds behind process-level switches (csrc/attention.hip): two query tiles per
-    walk with a lazily raised softmax reference (default), one tile per walk (VIDMEM_ATTN_PAIR=0), and the two-pass
-    softmax against the exact row maximum (VIDMEM_ATTN_ONLINE=0).  Same softmax in all three: the embeddings may
-    differ by the rounding of the 16-bit probabilities only.  The switches are read once per process, hence one child
-    process per variant."""
+    """The 577-token attention has three builds (csrc/attention.hip): two query tiles per walk with a lazily raised
+    softmax reference (what the release library runs), one tile per walk (VIDMEM_ATTN_PAIR=0), and the two-pass softmax
+    against the exact row maximum (VIDMEM_ATTN_ONLINE=0).  Same softmax in all three: the embeddings may differ by the
+    rounding of the 16-bit probabilities only.  The two other builds are reachable only in the DEVELOPER library
+    (make -C csrc dev: -DVM_DEV_SWITCHES; the release library reads no environment variable), where the switches are
+    read once per process, hence one child process per variant; skipped when that library has not been built."""
     import subprocess
     import sys
+    from vidmem import _lib
+    if not os.path.exists(_lib.DEV_LIB_PATH):
+        pytest.skip("libvidmem_dev.so not built (make -C real-time-brain-inspired-video-memory_amd/csrc dev)")
     prog = r'''
 import sys, numpy as np, torch
 sys.path.insert(0, sys.argv[1])
 import vidmem
+from vidmem import _lib
+_lib.use_dev_library()
 from vidmem import synthetic as syn
 from vidmem.encoder import FrameEncoder
 spec = dict(arch="t", image=336, patch=14, hidden=256, layers=2, heads=4, mlp=512, act="quick_gelu", ln_eps=1e-5,

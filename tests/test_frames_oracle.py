@@ -115,6 +115,71 @@ def test_extractor_sources_and_json_shape(tmp_path, monkeypatch):
     assert ex._stager.staged == 3 and ex._stager.shape == (16, 8, 8, 3)   # one staging per chunk, sized once
 
 
+def test_a_failing_group_stops_and_joins_the_staging_thread(tmp_path, monkeypatch):
+    """process_video reads and stages frames on a thread of its own, ahead of the launches.  When the main loop raises
+    (here: the encoder stand-in fails on the second group; in production a full non-ring memory, a top-k error, a failing
+    consumer) that thread must be stopped and JOINED before the source is released - a cv2.VideoCapture released during
+    a read on another thread can use freed memory - and no thread may be left behind."""
+    monkeypatch.chdir(tmp_path)
+    import asyncio
+    import threading
+    import time
+    from types import SimpleNamespace
+    from vidmem import extractor as X
+    events = []
+
+    class SlowSource(X._ArraySource):
+        def read_many(self, picks):
+            events.append(("read", threading.current_thread().name))
+            time.sleep(0.05)                       # the staging thread is inside a read when the consumer fails
+            return super().read_many(picks)
+
+        def release(self):
+            events.append(("release", threading.current_thread().name,
+                           [t.name for t in threading.enumerate() if t.name == "vidmem-stage"]))
+
+    class FailingEnc:
+        device = torch.device("cpu")
+        calls = 0
+
+        def embed_frames(self, frames):
+            FailingEnc.calls += 1
+            if FailingEnc.calls == 2:
+                raise RuntimeError("encoder failed on group 2")
+            return torch.zeros((frames.shape[0], 8))
+
+    class FakeMem:
+        searchable, ring, capacity = 0, False, 10 ** 9
+        def __init__(self): self.n = 0
+        def __len__(self): return self.n
+        def append(self, emb, ids=None, meta=None):
+            first = self.n; self.n += emb.shape[0]; return first
+        def id_of(self, r): return None
+
+    class HostStager:
+        def __init__(self, n, h, w, device): self.shape = (n, h, w, 3)
+        def stage(self, fr): return torch.from_numpy(np.ascontiguousarray(fr))
+        def get(self, ticket): return ticket
+        def done(self, ticket): pass
+
+    frames = np.zeros((16 * 12, 4, 4, 3), np.uint8)
+    monkeypatch.setattr(X, "open_source", lambda path: SlowSource(frames, 30.0))
+    cfg = SimpleNamespace(video=SimpleNamespace(chunk_size_seconds=16 / 30 + 1e-9, frames_per_chunk=16),
+                          encoder=SimpleNamespace(look_ahead_chunks=2, top_k=0))
+    ex = X.FrameEmbeddingExtractor(cfg, FailingEnc(), FakeMem(), top_k=0, stager_factory=HostStager)
+    before = threading.active_count()
+    with pytest.raises(RuntimeError, match="group 2"):
+        asyncio.run(ex.process_video("clip.fake", str(tmp_path / "out.json")))
+    assert threading.active_count() == before
+    rel = [e for e in events if e[0] == "release"]
+    assert len(rel) == 1 and rel[0][2] == [], "the source was released while the staging thread was alive"
+    assert all(e[1] == "vidmem-stage" for e in events if e[0] == "read")     # only that thread touches the source
+    # ... and the extractor is usable again afterwards
+    FailingEnc.calls = 10
+    out = asyncio.run(ex.process_video("clip.fake", str(tmp_path / "out.json")))
+    assert len(json.load(open(out))["results"]) == 12
+
+
 def test_cv2_source_branch_with_a_stand_in_module(tmp_path, monkeypatch):
     """``open_source`` on a real video path goes through ``_Cv2Source`` (cv2.VideoCapture + CAP_PROP_POS_FRAMES seeks,
     src/pipeline/vlm_extractor.py:32-39,108-111).  OpenCV is not installed in the build image, so a stand-in module with

@@ -7,10 +7,8 @@ from vidmem.encoder import FrameEncoder
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 spec = dict(specs.VIT_B16_224, layers=3)
 w = syn.encoder_weights(spec, seed=17)
-os.environ["VIDMEM_MICROBATCH"] = "64"
-plain = FrameEncoder(spec, w, "f16")
-os.environ["VIDMEM_ENC_DUAL"] = "1"
-dual = FrameEncoder(spec, w, "f16")
+plain = FrameEncoder(spec, w, "f16", schedule="one_stream", micro_batch=64)
+dual = FrameEncoder(spec, w, "f16", schedule="two_streams", micro_batch=64)
 bad = 0
 g = torch.Generator(device="cuda").manual_seed(3)
 for it in range(iters):
