@@ -47,8 +47,11 @@ def parse():
                          "1,048,576 = BASELINE configs[3], 8 M rows over 8 GPUs, when --gpus > 1)")
     ap.add_argument("--no-extractor", action="store_true", help="skip the plugin-path leg (process_video on a host clip)")
     ap.add_argument("--extractor-frames", type=int, default=4096)
-    ap.add_argument("--look-ahead-chunks", type=int, default=55, help="chunks per encoder call in the plugin-path leg")
+    ap.add_argument("--look-ahead-chunks", type=int, default=0,
+                    help="chunks per encoder call in the plugin-path leg (0 = auto, the config default: two encoder passes)")
     ap.add_argument("--no-two-stream", action="store_true", help="skip the one-stream A/B beside the main leg")
+    ap.add_argument("--schedule", default="auto", choices=["auto", "one_stream", "two_streams"],
+                    help="encoder schedule of the main leg (developer A/B; auto is the product default)")
     ap.add_argument("--no-ceiling", action="store_true", help="skip the mfma_ceiling leg (vm_probe_mfma)")
     ap.add_argument("--ceiling-seconds", type=float, default=1.5, help="seconds per vm_probe_mfma variant")
     ap.add_argument("--no-rccl-world1", action="store_true",
@@ -293,7 +296,7 @@ def main():
     D, k = spec["hidden"], args.topk
     F = args.chunks_per_step * 16
     weights = syn.encoder_weights(spec, seed=42)
-    enc = FrameEncoder(spec, weights, dtype="f16", device=local_rank)
+    enc = FrameEncoder(spec, weights, dtype="f16", device=local_rank, schedule=args.schedule)
     ctx = enc.ctx
 
     # memory shard: R L2-normalised rows (seed 7 + rank), ring so the size stays R while steps append
@@ -330,7 +333,7 @@ def main():
     # other stream's kernels.
     mb_frames = enc.micro_batch(F)          # frames per encoder pass (csrc/encoder.hip, micro_batch_of)
     passes = -(-F // mb_frames)
-    two_streams = passes >= 2               # what VM_SCHED_AUTO does with this step when timing is off
+    two_streams = passes >= 2 and args.schedule != "one_stream"   # what VM_SCHED_AUTO does with this step when timing is off
     per_step_events = passes * (7 * spec["layers"] + 8) + 16
     ctx.profile_enable(per_step_events + 64)
     step(args.warmup)
@@ -375,7 +378,7 @@ def main():
             emb_two = enc.embed_frames(frame_pool[0])
             enc.set_schedule("one_stream")
             emb_one = enc.embed_frames(frame_pool[0])
-            enc.set_schedule("auto")
+            enc.set_schedule(args.schedule)
             one_stream = {
                 "what": "the same steps on ONE stream (VM_SCHED_ONE_STREAM is what VM_SCHED_AUTO falls back to while "
                         "per-kernel timing is on; these are the steps roofline.avg_launch_ms was taken from, the "
@@ -683,7 +686,8 @@ def main():
             "workload": f"FrameEmbeddingExtractor.process_video on a {nfr}-frame 224x224 .npy clip (host file), chunks of "
                         f"16 frames, top-{k} + append per chunk against a memory of {R} rows that grows with the clip",
             "frames_per_s_look_ahead_1": ext[1],
-            "look_ahead_chunks": args.look_ahead_chunks, "frames_per_s": ext[args.look_ahead_chunks],
+            "look_ahead_chunks": args.look_ahead_chunks if args.look_ahead_chunks else "0 = auto (config default)",
+            "frames_per_s": ext[args.look_ahead_chunks],
             "fraction_of_value": ext[args.look_ahead_chunks] / value,
         }
 
@@ -806,16 +810,24 @@ def main():
         e3 = enc3.embed_frames(fr3[:2 * mb3])
         mem3.topk(e3[:16], k3)
         torch.cuda.synchronize()
-        # dominant GEMM instantiation of this leg, HIP-event timed inside the timed pass
-        ctx.profile_enable(F3 // mb3 * (7 * spec3["layers"] + 8) + 64)
-        ctx.profile_mask(["gemm_patch", "gemm_qkv", "gemm_resid"])
+        # the timed pass: the product's default schedule (two streams: the 10 passes alternate), no per-kernel events
         t0 = time.perf_counter()
         e3 = enc3.embed_frames(fr3)
         torch.cuda.synchronize()
         dt_enc = time.perf_counter() - t0
+        # the dominant GEMM instantiation's launch durations: the same frames again with its HIP events on (one stream
+        # while timing is on, as in the main leg)
+        ctx.profile_enable(F3 // mb3 * (7 * spec3["layers"] + 8) + 64)
+        ctx.profile_mask(["gemm_patch", "gemm_qkv", "gemm_resid"])
+        t0 = time.perf_counter()
+        e3b = enc3.embed_frames(fr3)
+        torch.cuda.synchronize()
+        dt_enc_one = time.perf_counter() - t0
         p3 = ctx.profile_read()
         ctx.profile_enable(0)
         ctx.profile_mask(None)
+        c3_same = bool(torch.equal(e3, e3b))
+        del e3b
         t0 = time.perf_counter()
         for i in range(20):
             mem3.topk(e3[16 * i:16 * i + 16], k3)
@@ -843,6 +855,9 @@ def main():
                         f"({passes3} encoder passes of {mb3}; a RATE, not the whole job); top-{k3} of 16 queries over "
                         f"{M3} x {D3} bf16",
             "frames_per_s": F3 / dt_enc, "encoder_tflops": F3 / dt_enc * specs.flops_per_frame(spec3, executed=True) / 1e12,
+            "encoder_schedule": "two streams (VM_SCHED_AUTO); one_stream_frames_per_s = the event-timed repeat the roofline "
+                                "was taken from",
+            "one_stream_frames_per_s": F3 / dt_enc_one, "embeddings_bit_identical": c3_same,
             "knn_queries_per_s": 16 / dt_knn, "knn_scan_GBps": M3 * D3 * 2 / dt_knn / 1e9,
             "uncertified_queries_redone": mem3.uncertified_count,
             "roofline": {"bound": "mfma", "kernel": "gemm256p_kernel<bf16, STORE16> (patch, QKV, proj, FC2)",

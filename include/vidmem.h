@@ -42,6 +42,7 @@ enum vm_layout { VM_LAYOUT_CHW = 0, VM_LAYOUT_PATCHES = 1 };
 /* Neo4j's vector.similarity.cosine (retriever_hybrid.py:296) is third-party and unpinned: the score mapping is
  * an explicit parameter instead of a guess.  RAW = cosine, UNIT_INTERVAL = (1 + cosine) / 2. */
 enum vm_score_mode { VM_SCORE_RAW = 0, VM_SCORE_UNIT_INTERVAL = 1 };
+enum vm_topk_flag { VM_FLAG_CERTIFIED = 0, VM_FLAG_GAP = 1, VM_FLAG_OVERFLOW = 3 };   /* out_query_flags values */
 
 /* ---- context ------------------------------------------------------------------------------------------ */
 int vm_init(int device, vm_ctx **out);
@@ -163,7 +164,10 @@ const void *vm_memory_rows(const vm_memory *mem); /* device pointer to the [capa
  * Two-stage: an fp32 MFMA scan keeps k+slack candidates per query, which are re-scored exactly.  A query whose
  * result cannot be PROVEN equal to the exhaustive answer (fp32 error bound vs the gap to the best rejected
  * row) is counted in *out_uncertified (device int32, accumulates, may be NULL) and marked in
- * out_query_flags[q] = 1 (device int32 [Q], rewritten for every query on every call, may be NULL).  Pass the flags
+ * out_query_flags[q] != 0 (device int32 [Q], rewritten for every query on every call, may be NULL; the value says
+ * why, vm_topk_flag: VM_FLAG_GAP = the exact k-th score does not clear the best rejected fp32 score by the error
+ * bound 2 (D + 8) 2^-24 - near-ties between rank k and rank k + slack, e.g. more than `slack` exact duplicates;
+ * VM_FLAG_OVERFLOW = more candidates at or above a query's cut than its buffer holds).  Pass the flags
  * to vm_topk_redo_flagged on the same stream: the reference always returns the exhaustive answer
  * (src/components/pre_llm_injector.py:356-370), so the pair {vm_topk_cosine, vm_topk_redo_flagged} is the drop-in. */
 size_t vm_topk_workspace_bytes(const vm_memory *mem, int Q, int k);

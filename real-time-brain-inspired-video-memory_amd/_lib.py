@@ -21,6 +21,7 @@ VM_F16, VM_BF16, VM_F32 = 0, 1, 2
 VM_ACT_GELU, VM_ACT_QUICK_GELU = 0, 1
 VM_LAYOUT_CHW, VM_LAYOUT_PATCHES = 0, 1
 VM_SCORE_RAW, VM_SCORE_UNIT_INTERVAL = 0, 1
+VM_FLAG_CERTIFIED, VM_FLAG_GAP, VM_FLAG_OVERFLOW = 0, 1, 3       # vm_topk_flag: why a query went to the exhaustive redo
 VM_ENC_OPT_SCHEDULE, VM_ENC_OPT_MICRO_BATCH, VM_ENC_OPT_LAST_LAYER = 0, 1, 2
 VM_SCHED_AUTO, VM_SCHED_ONE_STREAM, VM_SCHED_TWO_STREAMS = 0, 1, 2
 SCHEDULES = {"auto": VM_SCHED_AUTO, "one_stream": VM_SCHED_ONE_STREAM, "two_streams": VM_SCHED_TWO_STREAMS}

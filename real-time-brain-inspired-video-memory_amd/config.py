@@ -27,8 +27,9 @@ ENCODER_DEFAULTS: Dict[str, Any] = {
     "seed": 42,              # seed of the synthetic weights (no checkpoint can be fetched offline)
     "device": 0,
     "top_k": 5,              # neighbours reported per frame in the output JSON (`similar`)
-    "look_ahead_chunks": 1,  # chunks encoded per encoder call (extractor.py: same neighbours and rows as 1, bit for bit);
-                             # 0 = as many as fill one encoder pass within a staging budget (offline files)
+    "look_ahead_chunks": 0,  # chunks encoded per encoder call (extractor.py: same neighbours and rows as 1, bit for bit);
+                             # 0 (default) = as many as fill the encoder's passes within a staging budget; 1 = the
+                             # reference's one chunk in flight (src/pipeline/vlm_extractor.py:44-74: a live feed)
 }
 MEMORY_DEFAULTS: Dict[str, Any] = {
     "capacity": 100_000,     # rows resident in HBM (the reference caps its read-back at 5000: pre_llm_injector.py:398)

@@ -326,11 +326,34 @@ __device__ __forceinline__ void attend_tile_pass2(const char *kl, const char *vl
 // walk, 16 waves 26.0; pairs, 8 / 10 / 12 waves 27.4 (before the address trimming) / 28.3 / 24.9 - a 4 % gain, i.e.
 // the walk is not latency-bound; what it IS bound by has not been found (matrix pipe 24 % busy, LDS ~27 %, the
 // vector port ~65 % by instruction count; the K/V fill of a workgroup is 17 % of its life and overlaps nothing).
-template <int DT, int NT, bool EXACT>
+// ABL (developer library only, VIDMEM_ATTN_ABL): COMPILE-TIME ablations of the walk - 1 no exponentials, 2 no P.V MFMAs,
+// 4 no K/V fill (kernel), 8 no Q.K MFMAs, 16 no V fragment reads, 32 no K fragment reads.  (A first probe with RUNTIME
+// switches perturbed the kernel by 20 % with every switch off)  Results are garbage under any of them.
+// s_waitcnt vmcnt(n) for a wave-uniform n known only at run time (the count field is an immediate)
+__device__ __forceinline__ void wait_vmcnt_dyn(int n) {
+#define VM_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+    switch (n) {
+        VM_W(1) VM_W(2) VM_W(3) VM_W(4) VM_W(5) VM_W(6) VM_W(7) VM_W(8) VM_W(9) VM_W(10) VM_W(11) VM_W(12) VM_W(13)
+        VM_W(14) VM_W(15) VM_W(16) VM_W(17) VM_W(18) VM_W(19) VM_W(20) VM_W(21) VM_W(22) VM_W(23) VM_W(24) VM_W(25)
+        VM_W(26) VM_W(27) VM_W(28) VM_W(29) VM_W(30) VM_W(31) VM_W(32) VM_W(33) VM_W(34) VM_W(35) VM_W(36) VM_W(37)
+        VM_W(38) VM_W(39) VM_W(40) VM_W(41) VM_W(42) VM_W(43) VM_W(44) VM_W(45) VM_W(46) VM_W(47) VM_W(48)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // 0, and anything unexpected: wait for all
+    }
+#undef VM_W
+}
+
+// The K / V fill of a workgroup arrives in chunks of PAIR_CH_STEPS 32-key steps, issued by the workgroup's LOADER waves
+// (attention_pair_kernel); the other waves' FIRST walk meets the loaders at one barrier per chunk, right before the
+// first step that reads the chunk, so the walk overlaps the rest of the fill.
+constexpr int PAIR_CH_STEPS = 5;
+constexpr int PAIR_MAX_CH = 8;
+
+template <int DT, int NT, bool EXACT, int ABL = 0>
 __device__ __forceinline__ void attend_pair_online(const char *kl, const char *vl,
                                                    const typename vm_elem<DT>::vec8 (&qa)[2],
                                                    const typename vm_elem<DT>::vec8 (&qb)[2], int T, int lane,
-                                                   const bool (&qvalid)[2], uint16_t *const (&dst_row)[2]) {
+                                                   const bool (&qvalid)[2], uint16_t *const (&dst_row)[2],
+                                                   bool chunk_barriers = false) {
     using E = vm_elem<DT>;
     using vec8 = typename E::vec8;
     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -363,15 +386,25 @@ __device__ __forceinline__ void attend_pair_online(const char *kl, const char *v
     auto step = [&](int ks, bool masked0, bool has1, bool masked1) {
         const int hi_off = has1 ? 16 * 128 : 0;
         typedef const __attribute__((address_space(3))) vec8 *lds_vec8_ptr;
-        const vec8 ka0 = *(lds_vec8_ptr)(kp0);
-        const vec8 ka1 = *(lds_vec8_ptr)(kp1);
-        const vec8 kb0 = *(lds_vec8_ptr)(kp0 + (has1 ? 2048 : 0));
-        const vec8 kb1 = *(lds_vec8_ptr)(kp1 + (has1 ? 2048 : 0));
+        vec8 ka0, ka1, kb0, kb1;
+        if (ABL & 32) {
+            ka0 = ka1 = qa[0];
+            kb0 = kb1 = qb[0];
+        } else {
+            ka0 = *(lds_vec8_ptr)(kp0);
+            ka1 = *(lds_vec8_ptr)(kp1);
+            kb0 = *(lds_vec8_ptr)(kp0 + (has1 ? 2048 : 0));
+            kb1 = *(lds_vec8_ptr)(kp1 + (has1 ? 2048 : 0));
+        }
         s4v vlo[4], vhi[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-            vlo[dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr)(vp[dt]));
-            vhi[dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr)(vp[dt] + hi_off));
+            if (ABL & 16) {
+                vlo[dt] = vhi[dt] = __builtin_bit_cast(s4v, (unsigned long long)(0x3c003c003c003c00ull + dt));
+            } else {
+                vlo[dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr)(vp[dt]));
+                vhi[dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v_ptr)(vp[dt] + hi_off));
+            }
         }
         kp0 += 4096;
         kp1 += 4096;
@@ -384,10 +417,17 @@ __device__ __forceinline__ void attend_pair_online(const char *kl, const char *v
         bool out_of_slack = false;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            a[t][0] = E::mfma16(ka0, qa[t], f32x4{0.f, 0.f, 0.f, 0.f});
-            a[t][0] = E::mfma16(ka1, qb[t], a[t][0]);
-            a[t][1] = E::mfma16(kb0, qa[t], f32x4{0.f, 0.f, 0.f, 0.f});
-            a[t][1] = E::mfma16(kb1, qb[t], a[t][1]);
+            if (ABL & 8) {   // scores without the matrix pipe: something data-dependent and finite, one move each
+                const f32x4 ua = __builtin_bit_cast(f32x4, ka0), ub = __builtin_bit_cast(f32x4, kb0);
+                a[t][0] = f32x4{1.f, 2.f, 3.f, 4.f} + f32x4{ua[0] * 0.f, 0.f, 0.f, 0.f};
+                a[t][1] = f32x4{4.f, 3.f, 2.f, 1.f} + f32x4{ub[0] * 0.f, 0.f, 0.f, 0.f};
+                asm volatile("" : "+v"(a[t][0]), "+v"(a[t][1]) : "v"(ka1), "v"(kb1));
+            } else {
+                a[t][0] = E::mfma16(ka0, qa[t], f32x4{0.f, 0.f, 0.f, 0.f});
+                a[t][0] = E::mfma16(ka1, qb[t], a[t][0]);
+                a[t][1] = E::mfma16(kb0, qa[t], f32x4{0.f, 0.f, 0.f, 0.f});
+                a[t][1] = E::mfma16(kb1, qb[t], a[t][1]);
+            }
         }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -432,8 +472,10 @@ __device__ __forceinline__ void attend_pair_online(const char *kl, const char *v
             for (int u = 0; u < 2; ++u) {
                 f32x2 p01 = __builtin_elementwise_fma(f32x2{a[t][u][0], a[t][u][1]}, c2, n2[t]);
                 f32x2 p23 = __builtin_elementwise_fma(f32x2{a[t][u][2], a[t][u][3]}, c2, n2[t]);
-                p01 = f32x2{__builtin_amdgcn_exp2f(p01.x), __builtin_amdgcn_exp2f(p01.y)};
-                p23 = f32x2{__builtin_amdgcn_exp2f(p23.x), __builtin_amdgcn_exp2f(p23.y)};
+                if (!(ABL & 1)) {
+                    p01 = f32x2{__builtin_amdgcn_exp2f(p01.x), __builtin_amdgcn_exp2f(p01.y)};
+                    p23 = f32x2{__builtin_amdgcn_exp2f(p23.x), __builtin_amdgcn_exp2f(p23.y)};
+                }
                 sum2[t] += p01 + p23;
                 pe[4 * u + 0] = E::from_float(p01.x);
                 pe[4 * u + 1] = E::from_float(p01.y);
@@ -449,11 +491,19 @@ __device__ __forceinline__ void attend_pair_online(const char *kl, const char *v
         for (int dt = 0; dt < 4; ++dt)
             av[dt] = __builtin_bit_cast(vec8, __builtin_shufflevector(vlo[dt], vhi[dt], 0, 1, 2, 3, 4, 5, 6, 7));
         const vec8 pf0 = softmax_pack(0);
+        if (ABL & 2) {
+            asm volatile("" ::"v"(pf0), "v"(av[0]), "v"(av[1]), "v"(av[2]), "v"(av[3]));
+        } else {
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[0][dt] = E::mfma16(av[dt], pf0, o[0][dt]);
+            for (int dt = 0; dt < 4; ++dt) o[0][dt] = E::mfma16(av[dt], pf0, o[0][dt]);
+        }
         const vec8 pf1 = softmax_pack(1);
+        if (ABL & 2) {
+            asm volatile("" ::"v"(pf1));
+        } else {
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[1][dt] = E::mfma16(av[dt], pf1, o[1][dt]);
+            for (int dt = 0; dt < 4; ++dt) o[1][dt] = E::mfma16(av[dt], pf1, o[1][dt]);
+        }
         // schedule of the region above: (1 MFMA, 2 transcendentals) x 4 - tile 0's MFMAs over tile 1's exponentials
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -462,11 +512,20 @@ __device__ __forceinline__ void attend_pair_online(const char *kl, const char *v
         }
     };
     constexpr int FULL_STEPS = EXACT ? (NT - 1) / 2 : 0;
+    auto chunk_sync = [&](int ks) {   // first walk of a non-loader wave only; wave-uniform
+        if (chunk_barriers && ks % PAIR_CH_STEPS == 0) __builtin_amdgcn_s_barrier();
+    };
     int ks = 0;
 #pragma unroll 1
-    for (; ks < FULL_STEPS; ++ks) step(ks, false, true, false);
+    for (; ks < FULL_STEPS; ++ks) {
+        chunk_sync(ks);
+        step(ks, false, true, false);
+    }
 #pragma unroll 1
-    for (; ks < NS; ++ks) step(ks, true, 2 * ks + 1 < NT, true);
+    for (; ks < NS; ++ks) {
+        chunk_sync(ks);
+        step(ks, true, 2 * ks + 1 < NT, true);
+    }
 
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -492,7 +551,7 @@ __device__ __forceinline__ void attend_pair_online(const char *kl, const char *v
 // One workgroup of NW waves per (frame, head), every wave walks PAIRS of query tiles (attend_pair_online): pairs wave,
 // wave + NW, ...  With 37 tiles = 19 pairs and 12 waves seven waves take two pairs and five take one (16 waves with
 // one tile per walk: five waves take three tiles while eleven take two).
-template <int DT, int NT, bool EXACT, int NW>
+template <int DT, int NT, bool EXACT, int NW, int ABL = 0>
 __global__ void __launch_bounds__(NW * 64, 1)
     attention_pair_kernel(const uint16_t *__restrict__ qkv, uint16_t *__restrict__ ctx_out, int T, int heads,
                           int qt_lim) {
@@ -515,26 +574,62 @@ __global__ void __launch_bounds__(NW * 64, 1)
         q1 = __builtin_bit_cast(vec8, *reinterpret_cast<const uint4 *>(qp + 32 + 8 * h));
     };
     const int srow = lane >> 3, scp = lane & 7;
-    auto stage = [&](int part, char *dst) {  // rows past T re-read row T-1 (masked / P = 0 later)
-        const char *src = reinterpret_cast<const char *>(block(part));
-#pragma unroll 4
-        for (int grp = wave; grp < ROWS / 8; grp += NW) {
-            int key = grp * 8 + srow;
-            key = key > T - 1 ? T - 1 : key;
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + (size_t)key * 128 + ((scp ^ srow) << 4)),
-                                             (lds_ptr_t)(dst + grp * 1024), 16, 0, 2);  // nt: read once
-        }
-    };
+    // The fill: K and V rows by LDS-DMA (8 rows x 128 B per instruction), in CHUNKS of PAIR_CH_STEPS 32-key steps - chunk
+    // c = the K rows, then the V rows of steps [5c, 5c + 5).  It was 25 % of the kernel with nothing to overlap it (the
+    // whole workgroup waited for all of it; compile-time ablation table: DESIGN.md 4.3).  Now the LAST NL waves - with
+    // 19 pairs over 12 waves the ones that walk one pair where the others walk two - issue every unit up front and then
+    // retire chunk after chunk (counted vmcnt + the workgroup's barrier); the other waves start walking after chunk 0
+    // and meet the loaders at one barrier per chunk (attend_pair_online).  Why dedicated waves: hipcc puts an
+    // s_waitcnt vmcnt(0) in front of the first LDS read it sees while an LDS-DMA OF THE SAME WAVE may be in flight; a
+    // wave that issued none pays nothing for it.
+    constexpr int NS = (NT + 1) / 2;
+    constexpr int NCH = (NS + PAIR_CH_STEPS - 1) / PAIR_CH_STEPS;
+    static_assert(NCH <= PAIR_MAX_CH, "more fill chunks than the walk's barrier schedule knows");
+    constexpr int NL = NW >= 10 ? 5 : 3;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const bool loader = wave_u >= NW - NL;
     const int npairs = (qt_lim + 1) / 2;
     vec8 qa[2], qb[2];
-    if (wave < npairs) {
+    if (wave < npairs) {   // before the fill: older than every LDS-DMA in this wave's in-order stream
         load_q(2 * wave, qa[0], qb[0]);
         load_q(2 * wave + 1, qa[1], qb[1]);
     }
-    stage(1, kl);
-    stage(2, vl);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (loader) {
+        const char *srck = reinterpret_cast<const char *>(block(1));
+        const char *srcv = reinterpret_cast<const char *>(block(2));
+        int cum[PAIR_MAX_CH];   // units this wave has issued up to and including chunk c
+        int mine = 0, u = 0;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int g0 = c * PAIR_CH_STEPS * 4;
+            const int g1 = (c + 1) * PAIR_CH_STEPS * 4 < ROWS / 8 ? (c + 1) * PAIR_CH_STEPS * 4 : ROWS / 8;
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+                for (int grp = g0; grp < g1; ++grp, ++u) {
+                    if (u % NL != wave_u - (NW - NL) || (ABL & 4)) continue;
+                    int key = grp * 8 + srow;
+                    key = key > T - 1 ? T - 1 : key;   // rows past T re-read row T-1 (masked / P = 0 later)
+                    __builtin_amdgcn_global_load_lds(
+                        (gbl_ptr_t)((part ? srcv : srck) + (size_t)key * 128 + ((scp ^ srow) << 4)),
+                        (lds_ptr_t)((part ? vl : kl) + grp * 1024), 16, 0, 2);  // nt: read once
+                    ++mine;
+                }
+            }
+            cum[c] = mine;
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {   // everything of this wave's up to chunk c has landed -> tell the workgroup
+            wait_vmcnt_dyn(mine - cum[c]);
+            __builtin_amdgcn_s_barrier();
+        }
+        // a wait the COMPILER sees (free: everything has landed): without it, it assumes LDS-DMA in flight at the walks'
+        // first LDS read - for every wave, the branch being dynamic - and drains the next pair's query prefetch there
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
+    } else if (wave_u >= npairs) {   // no query tile of its own: still a partner in the fill's barriers
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) __builtin_amdgcn_s_barrier();
+    }
+    bool first = !loader;   // a loader's walks start behind the whole fill
     for (int pr = wave; pr < npairs; pr += NW) {
         bool qvalid[2];
         uint16_t *dst[2];
@@ -550,7 +645,8 @@ __global__ void __launch_bounds__(NW * 64, 1)
             load_q(2 * (pr + NW), qa[0], qb[0]);
             load_q(2 * (pr + NW) + 1, qa[1], qb[1]);
         }
-        attend_pair_online<DT, NT, EXACT>(kl, vl, ca, cb, T, lane, qvalid, dst);
+        attend_pair_online<DT, NT, EXACT, ABL>(kl, vl, ca, cb, T, lane, qvalid, dst, first);
+        first = false;
     }
 }
 
@@ -631,6 +727,22 @@ int launch_long(vm_ctx *ctx, const uint16_t *qkv, uint16_t *out, int B, int T, i
         }                                                                                                            \
         kern<<<B * heads, NWV * 64, lds, st>>>(qkv, out, T, heads, ql);                                              \
     }
+#ifdef VM_DEV_SWITCHES
+        static const int abl_env = (int)VM_DEV_ENV("ATTN_ABL", 0);
+#define VM_PAIR_ABL(A)                                                                                               \
+    if (abl_env == (A)) {                                                                                            \
+        auto kern = attention_pair_kernel<DT, NT, EXACT, 12, (A)>;                                                   \
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
+        kern<<<B * heads, 12 * 64, lds, st>>>(qkv, out, T, heads, ql);                                               \
+        VM_LAUNCH_CHECK(ctx);                                                                                        \
+        return VM_OK;                                                                                                \
+    }
+        if constexpr (NT == 37 && DT == VM_BF16) {
+            VM_PAIR_ABL(1) VM_PAIR_ABL(2) VM_PAIR_ABL(4) VM_PAIR_ABL(8) VM_PAIR_ABL(16) VM_PAIR_ABL(32) VM_PAIR_ABL(3)
+            VM_PAIR_ABL(10) VM_PAIR_ABL(48) VM_PAIR_ABL(63)
+        }
+#undef VM_PAIR_ABL
+#endif
         if (pair_env == 8) VM_PAIR_GO(8)
         else if (pair_env == 10) VM_PAIR_GO(10)
         else VM_PAIR_GO(12)

@@ -1,7 +1,40 @@
 // Context + frame preprocessing.
 #include "vm_internal.h"
 
+#include <cmath>
+#include <vector>
+
 static thread_local char g_init_err[256] = "";
+
+// The erf-GELU table of the FC1 epilogue (gemm.hip): entry i holds the minimax line {a, b} of Phi(x) = erfc(-x / sqrt 2) / 2
+// over [x_i - h/2, x_i + h/2], x_i = -5 + i h, h = 1/128 - the interval whose members round to index i.  The end
+// entries are the constants 0 and 1 (|x| >= 5 - h/2: x Phi(x) is within 1.5e-6 of 0 / x there).  In double precision on
+// the host, once per context; |x Phi(x) - x (a + b x)| <= 1.0e-6 |x| inside the table (h^2 / 16 x max |Phi''|).
+static void build_gelu_table(std::vector<float> &t) {
+    t.assign(VM_GELU_TAB_BYTES / 4, 0.f);
+    const double h = 1.0 / 128.0;
+    auto Phi = [](double x) { return 0.5 * std::erfc(-x * 0.70710678118654752440); };
+    for (int i = 0; i < VM_GELU_TAB_N; ++i) {
+        double a, b;
+        if (i == 0) {
+            a = 0.0, b = 0.0;
+        } else if (i == VM_GELU_TAB_N - 1) {
+            a = 1.0, b = 0.0;
+        } else {
+            const double xc = -5.0 + i * h, lo = xc - 0.5 * h, hi = xc + 0.5 * h;
+            b = (Phi(hi) - Phi(lo)) / (hi - lo);
+            double dmin = 1e300, dmax = -1e300;
+            for (int j = 0; j <= 64; ++j) {
+                const double x = lo + (hi - lo) * j / 64.0, d = Phi(x) - b * x;
+                dmin = d < dmin ? d : dmin;
+                dmax = d > dmax ? d : dmax;
+            }
+            a = 0.5 * (dmin + dmax);
+        }
+        t[2 * i] = (float)a;
+        t[2 * i + 1] = (float)b;
+    }
+}
 
 extern "C" int vm_abi_version(void) { return 4; }
 
@@ -31,6 +64,17 @@ extern "C" int vm_init(int device, vm_ctx **out) {
     ctx->prof_mask = 0xffffffffu;
     ctx->num_cus = prop.multiProcessorCount;
     ctx->err[0] = 0;
+    {
+        std::vector<float> tab;
+        build_gelu_table(tab);
+        if (hipMalloc((void **)&ctx->gelu_tab, VM_GELU_TAB_BYTES) != hipSuccess ||
+            hipMemcpy(ctx->gelu_tab, tab.data(), VM_GELU_TAB_BYTES, hipMemcpyHostToDevice) != hipSuccess) {
+            snprintf(g_init_err, sizeof(g_init_err), "device %d: GELU table allocation failed", device);
+            if (ctx->gelu_tab) (void)hipFree(ctx->gelu_tab);
+            delete ctx;
+            return VM_ERR_NOMEM;
+        }
+    }
     *out = ctx;
     return VM_OK;
 }
@@ -38,6 +82,7 @@ extern "C" int vm_init(int device, vm_ctx **out) {
 extern "C" void vm_destroy(vm_ctx *ctx) {
     if (!ctx) return;
     vm_profile_enable(ctx, 0);
+    if (ctx->gelu_tab) (void)hipFree(ctx->gelu_tab);
     delete ctx;
 }
 

@@ -25,6 +25,9 @@
 #ifndef VM_GEMM_X_AUX
 #define VM_GEMM_X_AUX 0
 #endif
+#ifndef VM_GELU_POLY
+#define VM_GELU_POLY 0   // 1: the round-2 erf-GELU (sigmoid of a polynomial, two transcendentals) for harness A/Bs
+#endif
 
 namespace {
 
@@ -60,6 +63,62 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
     r.x = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t.x));
     r.y = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t.y));
     return x * r;
+}
+
+// erf-GELU by TABLE (round 4).  The FC1 epilogue is VALU-bound: 65,536 GELUs per tile on two waves per SIMD with the
+// matrix pipe idle, ~54 issue cycles each in the form above (two 8-cycle transcendentals, eight packed or plain
+// 4-cycle instructions).  Phi(x) is smooth and bounded, so a piecewise-LINEAR table does it in six instructions and one
+// LDS read per element - v_med3 (clamp to the table), v_fma (index in the mantissa of 2^23 + ...), v_mad_u32_u24
+// (byte address), ds_read_b64 {a, b}, v_fma (Phi = a + b x), v_mul (x Phi) - with |error| <= 1.0e-6 |x| against the
+// 3.4e-6 of the polynomial form (table: context.hip build_gelu_table, 1,281 entries of 1/128 over [-5, 5], 10 KiB of
+// LDS per workgroup, copied from the context's device copy when the kernel starts).  x beyond the table takes the end
+// entries (Phi = 0 / 1); a NaN indexes entry 0 and comes out as NaN x 0 = NaN.
+__device__ __forceinline__ unsigned gelu_tab_addr(float x, unsigned tab_off) {
+    const float xc = __builtin_amdgcn_fmed3f(x, -5.0f, 5.0f);
+    const float m = __builtin_fmaf(xc, 128.0f, 8388608.0f + 640.0f);   // mantissa = round(128 x) + 640, ulp = 1
+    unsigned addr;   // low 24 bits of m = the mantissa (the exponent's lsb is 0): x 8 + table base in one instruction
+    asm("v_mad_u32_u24 %0, %1, 8, %2" : "=v"(addr) : "v"(m), "s"(tab_off));   // (hipcc turns __umul24(m, 8) + base into 3)
+    return addr;
+}
+typedef float tab2 __attribute__((ext_vector_type(2)));   // {a, b}: a FLOAT pair (bit_cast of a vector ELEMENT reads element 0)
+// y[e] = x[e] * fma(b[e], x[e], a[e]) for the four values of one accumulator block.  One asm statement: written in
+// C++, hipcc packs neighbours into v_pk_fma_f32 / v_pk_mul_f32 behind three v_mov that line the {a, b} pairs up (28
+// issue cycles per two elements instead of 16), and statement by statement it puts an s_nop behind each (same IEEE fma
+// and product in every form).
+__device__ __forceinline__ f32x4 gelu_tab_apply4(f32x4 x, const tab2 (&ab)[4]) {
+    float y0, y1, y2, y3;
+    asm("v_fma_f32 %0, %9, %4, %8\n\tv_fma_f32 %1, %11, %5, %10\n\tv_fma_f32 %2, %13, %6, %12\n\t"
+        "v_fma_f32 %3, %15, %7, %14\n\t"
+        "v_mul_f32 %0, %4, %0\n\tv_mul_f32 %1, %5, %1\n\tv_mul_f32 %2, %6, %2\n\tv_mul_f32 %3, %7, %3"
+        : "=&v"(y0), "=&v"(y1), "=&v"(y2), "=&v"(y3)
+        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(ab[0].x), "v"(ab[0].y), "v"(ab[1].x), "v"(ab[1].y),
+          "v"(ab[2].x), "v"(ab[2].y), "v"(ab[3].x), "v"(ab[3].y));
+    return f32x4{y0, y1, y2, y3};
+}
+// four lookups issued and retired in ONE asm statement (nothing the compiler could slip between issue and wait)
+__device__ __forceinline__ void gelu_tab_read4(tab2 (&ab)[4], const unsigned (&addr)[4]) {
+    asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %6\n\tds_read_b64 %3, %7\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(ab[0]), "=&v"(ab[1]), "=&v"(ab[2]), "=&v"(ab[3])
+                 : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3])
+                 : "memory");
+}
+// pipelined form for the persistent kernel's epilogue: issue now, retire two blocks later (counted lgkmcnt; other LGKM
+// traffic in flight only makes the wait stronger)
+__device__ __forceinline__ void gelu_tab_issue4(tab2 (&ab)[4], const unsigned (&addr)[4]) {
+    asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %6\n\tds_read_b64 %3, %7"
+                 : "=&v"(ab[0]), "=&v"(ab[1]), "=&v"(ab[2]), "=&v"(ab[3])
+                 : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3])
+                 : "memory");
+}
+template <int YOUNGER>
+__device__ __forceinline__ void gelu_tab_retire4(tab2 (&ab)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(ab[0]), "+v"(ab[1]), "+v"(ab[2]), "+v"(ab[3]) : "n"(YOUNGER) : "memory");
+}
+// workgroup-wide copy of the table into LDS (before any LDS-DMA of the kernel is issued)
+__device__ __forceinline__ void gelu_tab_to_lds(const float *tab, char *dst, int tid, int nthreads) {
+    for (int i = tid; i < VM_GELU_TAB_BYTES / 16; i += nthreads)
+        reinterpret_cast<uint4 *>(dst)[i] = reinterpret_cast<const uint4 *>(tab)[i];
 }
 
 // EPI_DELTA16 stores a bf16 encoder's residual-branch outputs as fp16 (vm_kernels.h): values beyond fp16's range - the
@@ -107,7 +166,8 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
 // All loads (bias, residual / position rows) are issued before the first use so they overlap instead of
 // serialising on one s_waitcnt each.
 template <int DT, int EPI, int NI>
-__device__ __forceinline__ void epilogue_row(const GemmArgs &g, const f32x4 (&a)[NI], int t, int fbase) {
+__device__ __forceinline__ void epilogue_row(const GemmArgs &g, const f32x4 (&a)[NI], int t, int fbase,
+                                             unsigned tab_off = 0) {
     using E = vm_elem<(EPI == EPI_DELTA16) ? VM_F16 : DT>;  // output element type
     float4 b4[NI];
 #pragma unroll
@@ -119,8 +179,18 @@ __device__ __forceinline__ void epilogue_row(const GemmArgs &g, const f32x4 (&a)
             f32x2 v01 = f32x2{a[i][0], a[i][1]} + f32x2{b4[i].x, b4[i].y};
             f32x2 v23 = f32x2{a[i][2], a[i][3]} + f32x2{b4[i].z, b4[i].w};
             if (EPI == EPI_GELU16) {
+#if VM_GELU_POLY
                 v01 = gelu_erf2(v01);
                 v23 = gelu_erf2(v23);
+#else
+                const unsigned ad[4] = {gelu_tab_addr(v01.x, tab_off), gelu_tab_addr(v01.y, tab_off),
+                                        gelu_tab_addr(v23.x, tab_off), gelu_tab_addr(v23.y, tab_off)};
+                tab2 ab[4];
+                gelu_tab_read4(ab, ad);
+                const f32x4 y = gelu_tab_apply4(f32x4{v01.x, v01.y, v23.x, v23.y}, ab);
+                v01 = f32x2{y[0], y[1]};
+                v23 = f32x2{y[2], y[3]};
+#endif
             }
             if (EPI == EPI_QGELU16) {
                 v01 = f32x2{quick_gelu(v01.x), quick_gelu(v01.y)};
@@ -182,12 +252,13 @@ __device__ __forceinline__ unsigned lds_offset(const void *p) {  // byte offset 
     return (unsigned)(size_t)(__attribute__((address_space(3))) const char *)p;
 }
 
+// bias_w: the wave's 128 bias values in LDS (the tile's slot + wave row x 128); tab_off: LDS byte offset of the GELU table
 template <int DT, int EPI, int NP, bool NOSTORE = false>
-__device__ __forceinline__ void epilogue16(const GemmArgs &g, const f32x4 (&acc)[8][NP], const float *bias_lds,
-                                           const char *scratch, int tbase, int fw, int lane) {
+__device__ __forceinline__ void epilogue16(const GemmArgs &g, const f32x4 (&acc)[8][NP], const float *bias_w,
+                                           const char *scratch, int tbase, int fw, int lane, unsigned tab_off) {
     using EO = vm_elem<(EPI == EPI_DELTA16) ? VM_F16 : DT>;  // output element type
     const int r16 = lane & 15, h = lane >> 4;
-    const unsigned b_off = lds_offset(bias_lds + fw + 4 * h);
+    const unsigned b_off = lds_offset(bias_w + 4 * h);
     const unsigned s_off = lds_offset(scratch);
     u32x4 braw[8];
     lds_rd128<0>(braw[0], b_off);
@@ -209,6 +280,34 @@ __device__ __forceinline__ void epilogue16(const GemmArgs &g, const f32x4 (&acc)
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
         u32x2 pk[8];
+        if (EPI == EPI_GELU16 && !VM_GELU_POLY) {
+            // table GELU, software-pipelined over the 8 feature blocks: block i's four lookups are issued two blocks
+            // before they are used, so their LDS latency (and bank conflicts: the addresses are data) hides under the
+            // index arithmetic and the products of the neighbouring blocks
+            f32x4 v[3];
+            tab2 ab[3][4];
+            auto issue = [&](int i) {
+                const f32x4 a = acc[i][p];
+                const f32x4 b = __builtin_bit_cast(f32x4, braw[i]);
+                const f32x2 v01 = f32x2{a[0], a[1]} + f32x2{b[0], b[1]};  // v_pk_add_f32
+                const f32x2 v23 = f32x2{a[2], a[3]} + f32x2{b[2], b[3]};
+                v[i % 3] = f32x4{v01.x, v01.y, v23.x, v23.y};
+                const unsigned ad[4] = {gelu_tab_addr(v01.x, tab_off), gelu_tab_addr(v01.y, tab_off),
+                                        gelu_tab_addr(v23.x, tab_off), gelu_tab_addr(v23.y, tab_off)};
+                gelu_tab_issue4(ab[i % 3], ad);
+            };
+            issue(0);
+            issue(1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (i + 2 < 8) issue(i + 2);
+                if (i + 2 < 8) gelu_tab_retire4<8>(ab[i % 3]);
+                else if (i + 1 < 8) gelu_tab_retire4<4>(ab[i % 3]);
+                else gelu_tab_retire4<0>(ab[i % 3]);
+                const f32x4 y = gelu_tab_apply4(v[i % 3], ab[i % 3]);
+                pk[i] = u32x2{EO::pack2(y[0], y[1]), EO::pack2(y[2], y[3])};
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const f32x4 a = acc[i][p];
@@ -228,6 +327,7 @@ __device__ __forceinline__ void epilogue16(const GemmArgs &g, const f32x4 (&acc)
                 v23 = sat_f16(v23);
             }
             pk[i] = u32x2{EO::pack2(v01.x, v01.y), EO::pack2(v23.x, v23.y)};  // v_cvt_pk_*
+        }
         }
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -270,6 +370,9 @@ __global__ void __launch_bounds__(512, 1) gemm256_kernel(GemmArgs g) {
     const int t0 = tm << 8, f0 = tn << 8;
     const int wr = wave >> 2, wc = wave & 3;  // wave row: 128 features; wave column: 64 tokens
     const int K = g.K, M = g.M;
+    constexpr bool TAB = EPI == EPI_GELU16 && !VM_GELU_POLY;
+    if (TAB) gelu_tab_to_lds(g.gelu_tab, smem + 8 * HALF_BYTES, tid, 512);   // visible after the K loop's barriers
+    const unsigned tab_off = lds_offset(smem + 8 * HALF_BYTES);
 
     // staging: per K-tile every wave issues 8 LDS-DMA instructions of 8 rows x 128 B, two from each REGION, where a
     // region is the set of rows all waves read in the same phase:
@@ -434,7 +537,7 @@ __global__ void __launch_bounds__(512, 1) gemm256_kernel(GemmArgs g) {
             for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(col[i]));
             continue;
         }
-        epilogue_row<DT, EPI, 8>(g, col, t, f0 + wr * 128 + 4 * h);
+        epilogue_row<DT, EPI, 8>(g, col, t, f0 + wr * 128 + 4 * h, tab_off);
     }
 }
 
@@ -605,10 +708,39 @@ __global__ void __launch_bounds__(512, 1) gemm256p_kernel(GemmArgs g) {
 
     int tile = vbid;
     if (tile >= ntiles) return;  // whole workgroup leaves together (grid <= ntiles, so this never splits a barrier)
-    // the whole bias vector sits in LDS behind the staging buffers: the epilogue then needs no vector-memory load
-    // (a load there would queue behind the LDS-DMA in flight and expose its full latency once per tile)
-    float *bias_lds = reinterpret_cast<float *>(smem + 8 * HALF_BYTES);
-    for (int i = tid; i < g.N; i += 512) bias_lds[i] = g.bias[i];
+    // XCD de-phasing (round 4, developer switch VIDMEM_GEMM_DEPHASE_PCT, off: MEASURED NULL).  Every CU walks tiles of
+    // the same cost from the same start, so all 256 reach their epilogues together and one round's 33 MB of output
+    // stores leave as one burst; the harness ablations price the stores at 97 us of FC1's 931 us launch (the whole
+    // epilogue arithmetic: 33 us).  Starting the eight XCDs an eighth of a tile time apart (the CUs that share operand
+    // panels share an XCD's L2 and stay in phase) was meant to spread that burst: 0 / 50 / 100 / 200 / 400 % of that
+    // stagger gave 954 / 956 / 962 / 971 / 981 us on FC1 and lost on every other shape (projection 239 -> 259 us at
+    // 100 %): the stores' cost is not the lockstep burst.
+    if (g.dephase_ticks > 0) {
+        const unsigned long long wait = (unsigned long long)(blockIdx.x & 7) * g.dephase_ticks;   // 100 MHz ticks
+        const unsigned long long t_start = wall_clock64();
+        while (wall_clock64() - t_start < wait) __builtin_amdgcn_s_sleep(16);
+    }
+    // LDS behind the staging buffers: [2 bias slots of 1 KiB][8 x 2 KiB epilogue scratch][GELU table].
+    // The 256 bias values of a TILE arrive by one LDS-DMA instruction (64 lanes x 16 B, wave 0) in the slot of the
+    // tile's parity, issued a whole tile ahead (prologue: tile 0; boundary n: tile n + 1, ahead of the prestage), so the
+    // epilogue needs no vector-memory load (it would queue behind the LDS-DMA in flight and expose its full latency
+    // once per tile) and the whole bias vector no longer takes the 12-16 KiB the table now needs.  One more operation
+    // in wave 0's in-order stream only makes its counted waits stronger.
+    char *bias_slots = smem + 8 * HALF_BYTES;
+    char *scratch_base = bias_slots + 2048;
+    constexpr bool TAB = EPI == EPI_GELU16 && !VM_GELU_POLY;
+    if (TAB) gelu_tab_to_lds(g.gelu_tab, scratch_base + 16384, tid, 512);   // before any LDS-DMA: plain stores
+    const unsigned tab_off = lds_offset(scratch_base + 16384);
+    auto stage_bias = [&](int tile_, int slot) {
+        if (OUT16 && wave == 0) {
+            int tm_, tn_;
+            tile_coords(tile_, tm_, tn_);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(g.bias + (tn_ << 8) + lane * 4),
+                                             (lds_ptr_t)(bias_slots + slot * 1024), 16, 0, 0);
+        }
+    };
+    int tcount = 0;   // tiles finished by this workgroup (bias slot = parity)
+    stage_bias(tile, 0);
     if (ABL & 128) {  // ablation: start the workgroups of an XCD in 4 groups, g.P x 10 ns apart (epilogue bursts desynchronised)
         const int grp = (blockIdx.x >> 3) & 3;
         const unsigned long long t_start = __builtin_readcyclecounter();
@@ -711,6 +843,7 @@ __global__ void __launch_bounds__(512, 1) gemm256p_kernel(GemmArgs g) {
         // the consumed buffer is free (every wave's reads of it retired before this barrier): stage K-tile 1 of the
         // next tile into it NOW, ahead of the epilogue's stores in this CU's in-order memory pipe
         const bool do_prestage = has_next && nk >= 2;
+        if (has_next) stage_bias(next_tile, (tcount + 1) & 1);
         if (do_prestage) {
             const int cb = (gk + 1) & 1;  // == buffer of the K-tile just consumed
             stage_Wa0(1, cb);
@@ -732,10 +865,11 @@ __global__ void __launch_bounds__(512, 1) gemm256p_kernel(GemmArgs g) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
             } else if (OUT16) {
-                // 2 KiB of wave-private scratch each in the spare LDS behind the bias table: 8 token rows per pass
-                const char *scratch = smem + 8 * HALF_BYTES + ((g.N * 4 + 15) & ~15) + (wr * 4 + wc) * 2048;
-                if (ABL & 8) epilogue16<DT, EPI, 4, true>(g, acc, bias_lds, scratch, t0 + wc * 64, f0 + wr * 128, lane);
-                else epilogue16<DT, EPI, 4>(g, acc, bias_lds, scratch, t0 + wc * 64, f0 + wr * 128, lane);
+                // 2 KiB of wave-private scratch each in the spare LDS behind the bias slots: 8 token rows per pass
+                const char *scratch = scratch_base + (wr * 4 + wc) * 2048;
+                const float *bias_w = reinterpret_cast<const float *>(bias_slots + (tcount & 1) * 1024) + wr * 128;
+                if (ABL & 8) epilogue16<DT, EPI, 4, true>(g, acc, bias_w, scratch, t0 + wc * 64, f0 + wr * 128, lane, tab_off);
+                else epilogue16<DT, EPI, 4>(g, acc, bias_w, scratch, t0 + wc * 64, f0 + wr * 128, lane, tab_off);
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -748,6 +882,7 @@ __global__ void __launch_bounds__(512, 1) gemm256p_kernel(GemmArgs g) {
             }
         }
         if (wr == 1) VM_BAR();
+        ++tcount;
         if (!has_next) break;
         {   // how many stores did this wave's epilogue leave in the pipe?  exact only for a full 16-bit tile
             int tm_done, tn_done;
@@ -786,6 +921,9 @@ __global__ void __launch_bounds__(256, 2) gemm128_kernel(GemmArgs g) {
     const int t0 = tm << 7, f0 = tn << 7;
     const int wf = wave & 1, wt = wave >> 1;
     const int K = g.K, M = g.M;
+    constexpr bool TAB = EPI == EPI_GELU16 && !VM_GELU_POLY;
+    if (TAB) gelu_tab_to_lds(g.gelu_tab, smem + 4 * HALF_BYTES, tid, 256);   // visible after the K loop's barriers
+    const unsigned tab_off = lds_offset(smem + 4 * HALF_BYTES);
 
     const int srow = lane >> 3, scp = lane & 7;
     const uint16_t *wsrc[4], *xsrc[4];
@@ -849,7 +987,7 @@ __global__ void __launch_bounds__(256, 2) gemm128_kernel(GemmArgs g) {
         f32x4 col[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) col[i] = acc[i][j];
-        epilogue_row<DT, EPI, 4>(g, col, t, f0 + wf * 64 + 4 * h);
+        epilogue_row<DT, EPI, 4>(g, col, t, f0 + wf * 64 + 4 * h, tab_off);
     }
 }
 
@@ -859,6 +997,7 @@ template <int DT, int EPI>
 int launch_epi(vm_ctx *ctx, const GemmArgs &g, hipStream_t st) {
     static const int env_variant = (int)VM_DEV_ENV("GEMM", 0);
     const int variant = g_variant ? g_variant : env_variant;
+    constexpr size_t TAB_LDS = (EPI == EPI_GELU16 && !VM_GELU_POLY) ? VM_GELU_TAB_BYTES : 0;   // the GELU table in LDS
     const int tiles256 = ((g.M + 255) / 256) * (g.N / 256);
     // the 256 x 256 kernels address a tile through 32-bit byte offsets inside per-tile descriptors (gemm_guard.h)
     const bool big_ok = g.N % 256 == 0 && vm_gemm256_tile_addressable(g.K, g.ldx);
@@ -866,7 +1005,7 @@ int launch_epi(vm_ctx *ctx, const GemmArgs &g, hipStream_t st) {
     const bool use256 = (variant == 2 || variant == 3) ? big_ok : (variant == 1 ? false : (big_ok && tiles256 * 10 >= ctx->num_cus * 8));
 #ifdef VM_GEMM_ABLATE
     if (variant >= 1024 && DT == VM_F16) {  // persistent-kernel ablations: 1024 + ABL bits: 1024 + 8 (no stores) / + 16 (no epilogue)
-        const size_t lds = 8 * HALF_BYTES + (size_t)g.N * 4 + 16384;
+        const size_t lds = 8 * HALF_BYTES + 2048 + 16384 + TAB_LDS;
         const int grid = tiles256 < ctx->num_cus ? tiles256 : ctx->num_cus;
 #define ABLP(A)                                                                                                   \
     if (variant == 1024 + (A)) {                                                                                  \
@@ -908,7 +1047,7 @@ int launch_epi(vm_ctx *ctx, const GemmArgs &g, hipStream_t st) {
     if (use256 && variant != 2 && g.N <= 4096) {
         auto kern = gemm256p_kernel<DT, EPI>;
         static unsigned long long attr_set_p = 0;   // one bit per device
-        const size_t lds = 8 * HALF_BYTES + (size_t)g.N * 4 + 16384;  // staging + bias table + epilogue scratch
+        const size_t lds = 8 * HALF_BYTES + 2048 + 16384 + TAB_LDS;  // staging + bias slots + epilogue scratch (+ table)
         if (!((attr_set_p >> (ctx->device & 63)) & 1ull)) {
             VM_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             163840));
@@ -919,7 +1058,7 @@ int launch_epi(vm_ctx *ctx, const GemmArgs &g, hipStream_t st) {
     } else if (use256) {
         auto kern = gemm256_kernel<DT, EPI>;
         static unsigned long long attr_set = 0;   // one bit per device
-        const size_t lds = 8 * HALF_BYTES;
+        const size_t lds = 8 * HALF_BYTES + TAB_LDS;
         if (!((attr_set >> (ctx->device & 63)) & 1ull)) {
             VM_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr_set |= 1ull << (ctx->device & 63);
@@ -928,7 +1067,7 @@ int launch_epi(vm_ctx *ctx, const GemmArgs &g, hipStream_t st) {
     } else {
         auto kern = gemm128_kernel<DT, EPI>;
         static unsigned long long attr_set = 0;   // one bit per device
-        const size_t lds = 4 * HALF_BYTES;
+        const size_t lds = 4 * HALF_BYTES + TAB_LDS;
         if (!((attr_set >> (ctx->device & 63)) & 1ull)) {
             VM_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr_set |= 1ull << (ctx->device & 63);
@@ -967,6 +1106,16 @@ int vm_gemm(vm_ctx *ctx, int dtype, const GemmArgs &g, int epi, hipStream_t st) 
     a.stream_out = (size_t)g.M * g.N * 2 > ((size_t)32 << 20);  // more than the 8 x 4 MiB of L2
     if (a.hm_rows <= 0) a.hm_rows = g.M;
     if (a.hm_stride <= 0) a.hm_stride = 1;
+    a.gelu_tab = ctx ? ctx->gelu_tab : nullptr;
+    {   // XCD de-phasing of the persistent kernel: an eighth of one tile's time per XCD slot (gemm256p_kernel).  A tile
+        // is 2 x 256 x 256 x K FLOP at ~3.4 TFLOP/s per CU (what the K loop sustains); launches of fewer than four
+        // rounds of tiles keep the common start (the stagger would be a visible tail).  100 MHz wall-clock ticks.
+        static const long pct = VM_DEV_ENV("GEMM_DEPHASE_PCT", 0);   // measured null (gemm256p_kernel): off
+        const double tile_us = 2.0 * 256 * 256 * g.K / 3.4e6;
+        const double rounds = (double)((g.M + 255) / 256) * (g.N / 256) / (ctx ? ctx->num_cus : 256);
+        a.dephase_ticks = (pct > 0 && rounds >= 4.0) ? (int)(tile_us * 100.0 / 8.0 * pct / 100.0) : 0;
+    }
+    if (epi == EPI_GELU16 && !a.gelu_tab) return vm_fail(ctx, VM_ERR_INVALID, "vm_gemm: GELU epilogue needs a context");
     {   // feature-tile groups of the persistent 256 x 256 kernel (gemm256p_kernel, "Tile order")
         // weight bytes an XCD's L2 keeps beside the streams; 0 = off
         static const long budget = VM_DEV_ENV("GEMM_WGROUP_KB", 2560) * 1024;

@@ -629,14 +629,14 @@ __global__ void __launch_bounds__(FIN_THREADS)
             const bool all_rows_are_candidates = rv.n <= (int64_t)nfin;
             if (mark && mark[q]) {  // emit scan: candidate buffer overflowed / unranked ties -> exhaustive redo
                 if (uncertified) atomicAdd(uncertified, 1);
-                if (qflags) qflags[q] = 1;
+                if (qflags) qflags[q] = VM_FLAG_OVERFLOW;
             } else if (!all_rows_are_candidates && qn != 0.0) {
                 const float bound_f32 = fs[KL - 1];  // best possible fp32 score of a rejected row (x 1/||q||)
                 const double eps = 2.0 * (double)(D + 8) * 5.9604644775390625e-08;  // 2*(D+8)*2^-24
                 const double reject = (double)bound_f32 / qn + eps;
                 if (!(e > reject)) {
                     if (uncertified) atomicAdd(uncertified, 1);
-                    if (qflags) qflags[q] = 1;
+                    if (qflags) qflags[q] = VM_FLAG_GAP;
                 }
             }
         }
@@ -786,7 +786,12 @@ int run_topk_kl(vm_memory *m, const ScanPlan &p, const void *queries, int Q, int
         int *mk = (int *)((char *)cand_cnt + vm_align_up((size_t)p.q_pad * 4, 256));
         float *cand_s = (float *)((char *)mk + vm_align_up((size_t)p.q_pad * 4, 256));
         int *cand_o = (int *)((char *)cand_s + vm_align_up((size_t)p.q_pad * VM_EMIT_CAP * 4, 256));
-        static const int growth = VM_DEV_ENV("CUT_GROWTH", 8) < 2 ? 2 : (int)VM_DEV_ENV("CUT_GROWTH", 8);
+        // growth of the pass limits: 8 for many queries (a pass emits ~ln(growth) KL candidates per query and every
+        // candidate is matrix-pipe time there); 32 when one superblock of <= 128 queries scans at the HBM rate, where a
+        // pass costs its two launches (scan + compact, ~25 us) and nothing else: 3 passes instead of 4 over 1 M rows
+        static const int growth_many = VM_DEV_ENV("CUT_GROWTH", 8) < 2 ? 2 : (int)VM_DEV_ENV("CUT_GROWTH", 8);
+        static const int growth_few = VM_DEV_ENV("CUT_GROWTH_FEW", 32) < 2 ? 2 : (int)VM_DEV_ENV("CUT_GROWTH_FEW", 32);
+        const int growth = Q <= 128 ? growth_few : growth_many;
         // cand_cnt and mk are neighbours: one memset clears both
         hipError_t e = hipMemsetAsync(cand_cnt, 0, 2 * vm_align_up((size_t)p.q_pad * 4, 256), st);
         if (e != hipSuccess) return vm_fail(m->ctx, VM_ERR_HIP, "memset: %s", hipGetErrorString(e));

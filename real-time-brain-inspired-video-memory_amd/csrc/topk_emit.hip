@@ -576,7 +576,12 @@ bool vm_topk_emit_supported(const vm_memory *m, int Q, int KL) {
     if (!env) return false;
     const int ks = m->D / 128;
     const bool d_ok = m->D % 128 == 0 && (ks == 1 || ks == 2 || ks == 4 || ks == 6 || ks == 8);
-    return d_ok && Q >= 49 && KL <= 64 && m->cap >= 65536;
+    // From 49 queries on, and - round 4 - for any query count once the per-lane lists would hold 32 or 64 entries
+    // (k >= 11): a lane of the list scan sees ~120 scores of a 1 M-row memory, so a 32-entry sorted list is all warm-up
+    // (75 of 120 scores pay a 256-instruction insert) and the scan is VALU-bound at 0.47 of the HBM rate (top-20 over
+    // 1 M x 1024 bf16, BASELINE configs[2]); the emit scan compares a score with the query's cut and is HBM-bound.
+    static const int kl32 = (int)VM_DEV_ENV("EMIT_KL32", 1);
+    return d_ok && (Q >= 49 || (kl32 && KL >= 32)) && KL <= 64 && m->cap >= 65536;
 }
 
 size_t vm_topk_emit_workspace_bytes(int q_pad) {

@@ -277,21 +277,18 @@ __global__ void __launch_bounds__(512, 1) topk_gscan_kernel(GscanArgs g) {
         const unsigned ctb = tab + 1024 + (wc * 64 + r16) * 4;   // + 64 j
         u32x4 rn[8];
         unsigned ct[4];
-        lds_rd128<0>(rn[0], rnb);
-        lds_rd128<64>(rn[1], rnb);
-        lds_rd128<128>(rn[2], rnb);
-        lds_rd128<192>(rn[3], rnb);
-        lds_rd128<256>(rn[4], rnb);
-        lds_rd128<320>(rn[5], rnb);
-        lds_rd128<384>(rn[6], rnb);
-        lds_rd128<448>(rn[7], rnb);
-        lds_rd32<0>(ct[0], ctb);
-        lds_rd32<64>(ct[1], ctb);
-        lds_rd32<128>(ct[2], ctb);
-        lds_rd32<192>(ct[3], ctb);
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(rn[0]), "+v"(rn[1]), "+v"(rn[2]), "+v"(rn[3]), "+v"(rn[4]), "+v"(rn[5]), "+v"(rn[6]),
-                       "+v"(rn[7]), "+v"(ct[0]), "+v"(ct[1]), "+v"(ct[2]), "+v"(ct[3]));
+        // the twelve reads and their wait in ONE asm statement: the compiler's waitcnt insertion does not see asm-issued
+        // LDS reads, so nothing - no copy, no spill of a destination - may come between the issue and the wait
+        asm volatile(
+            "ds_read_b128 %0, %12\n\tds_read_b128 %1, %12 offset:64\n\tds_read_b128 %2, %12 offset:128\n\t"
+            "ds_read_b128 %3, %12 offset:192\n\tds_read_b128 %4, %12 offset:256\n\tds_read_b128 %5, %12 offset:320\n\t"
+            "ds_read_b128 %6, %12 offset:384\n\tds_read_b128 %7, %12 offset:448\n\t"
+            "ds_read_b32 %8, %13\n\tds_read_b32 %9, %13 offset:64\n\tds_read_b32 %10, %13 offset:128\n\t"
+            "ds_read_b32 %11, %13 offset:192\n\ts_waitcnt lgkmcnt(0)"
+            : "=&v"(rn[0]), "=&v"(rn[1]), "=&v"(rn[2]), "=&v"(rn[3]), "=&v"(rn[4]), "=&v"(rn[5]), "=&v"(rn[6]),
+              "=&v"(rn[7]), "=&v"(ct[0]), "=&v"(ct[1]), "=&v"(ct[2]), "=&v"(ct[3])
+            : "v"(rnb), "v"(ctb)
+            : "memory");
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int qj = q0 + wc * 64 + 16 * j + r16;

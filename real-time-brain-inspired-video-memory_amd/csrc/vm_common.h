@@ -35,7 +35,13 @@ struct vm_ctx {
     uint32_t prof_mask;
     double prof_ms[VM_PROF_NCAT];
     int64_t prof_launches[VM_PROF_NCAT];
+    // erf-GELU table of the FC1 epilogue (gemm.hip gelu_tab_*; built in vm_init, context.hip): VM_GELU_TAB_N pairs
+    // {a, b} with Phi(x) ~ a + b x on the 1/128-wide interval around x = -5 + i/128, device memory
+    float *gelu_tab;
 };
+
+constexpr int VM_GELU_TAB_N = 1281;                 // x = -5 ... +5 in steps of 1/128
+constexpr int VM_GELU_TAB_BYTES = 10256;            // 1281 x 8 B, padded to whole 16-byte pieces
 
 // Brackets the launches inside a scope with two events when profiling is on; free when it is off.
 struct vm_prof_scope {

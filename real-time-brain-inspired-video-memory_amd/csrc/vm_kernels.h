@@ -31,6 +31,8 @@ struct GemmArgs {
     int stream_out;     // set by vm_gemm: the 16-bit output is larger than L2 and leaves with the non-temporal policy
     int fgroup;         // set by vm_gemm: feature tiles per group of the persistent kernel's tile order (0 = all)
     int explicit_zero;  // set by vm_gemm (developer A/B, VIDMEM_GEMM_ZERO=1): clear accumulators per tile instead of C = 0
+    const float *gelu_tab;  // set by vm_gemm: the context's erf-GELU table (EPI_GELU16 only)
+    int dephase_ticks;      // set by vm_gemm: start delay per XCD slot of the persistent kernel, 100 MHz ticks (0 = none)
 };
 
 int vm_gemm(vm_ctx *ctx, int dtype, const GemmArgs &g, int epi, hipStream_t st);

@@ -182,16 +182,19 @@ class FrameEmbeddingExtractor:
             self._stager.close()
         self._stager = None
 
-    def _auto_look_ahead(self, src, frames_per_chunk: int, slot_bytes: int = 256 << 20) -> int:
-        """``look_ahead_chunks: 0``: as many chunks per group as fill one encoder pass (FrameEncoder.micro_batch: 883
-        frames of ViT-B/16, 224 of CLIP-L/14-336), as long as one staging slot of the group's source frames stays under
-        ``slot_bytes`` of pinned host memory (two such slots exist, and two on the device: 1080p frames are 6.2 MB each).
-        A source that does not say its frame size, or an encoder stand-in without ``micro_batch``, gets 1."""
+    def _auto_look_ahead(self, src, frames_per_chunk: int, slot_bytes: int = 320 << 20) -> int:
+        """``look_ahead_chunks: 0`` (the default): as many chunks per group as fill the encoder's passes
+        (FrameEncoder.micro_batch: 883 frames of ViT-B/16, 224 of CLIP-L/14-336) - TWO passes when the encoder runs its
+        two-stream schedule (two passes of one call side by side, include/vidmem.h VM_ENC_OPT_SCHEDULE), one otherwise -
+        as long as one staging slot of the group's source frames stays under ``slot_bytes`` of pinned host memory (two
+        such slots exist, and two on the device: 1080p frames are 6.2 MB each).  A source that does not say its frame
+        size, or an encoder stand-in without ``micro_batch``, gets 1."""
         hw = getattr(src, "frame_hw", None)
         mb = getattr(self.encoder, "micro_batch", None)
         if hw is None or mb is None or frames_per_chunk <= 0:
             return 1
-        by_pass = int(mb(10 ** 6)) // frames_per_chunk
+        passes = 2 if getattr(self.encoder, "schedule", "one_stream") != "one_stream" else 1
+        by_pass = passes * int(mb(10 ** 6)) // frames_per_chunk
         by_bytes = slot_bytes // max(1, frames_per_chunk * int(hw[0]) * int(hw[1]) * 3)
         return max(1, min(by_pass, by_bytes))
 
@@ -241,7 +244,7 @@ class FrameEmbeddingExtractor:
                                             video_cfg.frames_per_chunk)
             results = []
             result_lines: List[str] = []      # results[i] as JSON text (finish)
-            # Look-ahead groups (config.encoder.look_ahead_chunks, default 1 = the reference's one chunk at a time, 0 = auto,
+            # Look-ahead groups (config.encoder.look_ahead_chunks, default 0 = auto, 1 = the reference's one chunk at a time,
             # :44-74): the frames of N consecutive chunks go through ONE encoder call - the encoder fills the chip only
             # from a few hundred frames up - and then every chunk of the group, in chunk order, gets its own top-k
             # against the memory as it stands (chunks < i, the group's earlier chunks included) followed by its own

@@ -249,6 +249,8 @@ def test_array_source_group_reads(tmp_path):
     assert src.frame_hw == (6, 5) and ex._auto_look_ahead(src, 16) == 55
     assert ex._auto_look_ahead(src, 16, slot_bytes=16 * 6 * 5 * 3 * 7 + 1) == 7        # the budget binds
     big = type("S", (), {"frame_hw": (1080, 1920)})()
-    assert ex._auto_look_ahead(big, 16) == 2                                           # 16 x 6.2 MB per chunk
+    assert ex._auto_look_ahead(big, 16) == 3                                           # 16 x 6.2 MB per chunk
+    ex.encoder = type("E", (), {"micro_batch": staticmethod(lambda b: min(b, 883)), "schedule": "auto"})()
+    assert ex._auto_look_ahead(src, 16) == 110                                         # two passes side by side
     ex.encoder = object()
     assert ex._auto_look_ahead(src, 16) == 1 and ex._auto_look_ahead(type("S", (), {})(), 16) == 1

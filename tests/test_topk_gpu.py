@@ -131,6 +131,44 @@ def test_many_exact_ties_fall_back_to_exhaustive():
     assert set(r0[0].tolist()) <= set(range(100, 140))
 
 
+def test_the_shape_that_must_redo_near_ties_around_rank_k():
+    """The one configuration the fast path REFUSES to certify without its candidate buffers overflowing, pinned down in
+    round 4 (tools/uncert_probe.py: a clip processed twice - every stored row twice - made the 10th and the 17th best
+    score of a per-chunk search 9.2e-5 apart): the exact k-th score must clear the best score a KL-entry list can have
+    REJECTED by the fp32 error bound 2 (D + 8) 2^-24; with KL - k + 1 or more rows within that bound of rank k it
+    cannot, whatever the scan variant.  Such a query is flagged VM_FLAG_GAP (1, not the overflow code 3), redone
+    exhaustively on the device, and the answer is the reference's.  Fewer near-ties than the slack: certified."""
+    from vidmem import _lib
+    rng = np.random.default_rng(21)
+    D, k = 256, 10                                            # k = 10 -> lists of KL = 16: six ranks of slack
+    base = torch.tensor(rng.standard_normal(D), dtype=torch.float32).to(torch.float16)
+
+    def variants(n):      # rows one fp16 ulp away from `base` in one element each: cosines within ~1e-7 of 1, all different
+        v = base.repeat(n, 1).clone()
+        bits = v.view(torch.int16)
+        for j in range(n):
+            bits[j, 3 * j + 1] += 1
+        return v
+    for near, must_redo in ((20, True), (5, False)):
+        m = torch.tensor(rng.standard_normal((500, D)), dtype=torch.float32).to(torch.float16)
+        m[200] = base
+        m[300:300 + near] = variants(near)
+        mem = _mem("f16", 512, D)
+        mem.append(m)
+        q = torch.stack([base, m[7]])                         # query 1 is an ordinary one
+        s, r = mem.topk(q, k)
+        flags = mem._scratch.flags[:2].cpu().tolist()
+        want_r, want_s = cref.cosine_topk(_bits(q), _bits(m), k, dtype="f16")
+        assert np.array_equal(r.cpu().numpy(), want_r) and np.array_equal(s.cpu().numpy(), want_s)
+        assert flags[1] == 0
+        if must_redo:
+            assert flags[0] == _lib.VM_FLAG_GAP and mem.uncertified_count == 1
+            gap = float(want_s[0, k - 1] - np.sort(cref.cosine_matrix(_bits(q[:1]), _bits(m), dtype="f16")[0])[::-1][16])
+            assert 0.0 <= gap < 2.0 * (D + 8) * 2.0 ** -24       # that is WHY: rank k and rank KL + 1 within the bound
+        else:
+            assert flags[0] == 0 and mem.uncertified_count == 0
+
+
 @pytest.mark.parametrize("dtype,D", [("f16", 256), ("bf16", 1024)])
 def test_flagged_redo_only_touches_flagged_queries(dtype, D):
     """A batch where SOME queries are uncertifiable (40 exact ties, near-ties below the fp32 bound) and the others

@@ -1,8 +1,9 @@
 """Developer probe: encoder passes over synthetic frames with the per-kernel HIP-event breakdown.
-   python tools/enc_probe.py [arch=vit_b16_224|clip_l14_336] [dtype=f16|bf16] [frames] [iters]"""
+   python tools/enc_probe.py [arch=vit_b16_224|clip_l14_336] [dtype=f16|bf16] [frames] [iters] [layers]"""
 import sys, time, torch
 sys.path.insert(0, ".")
 import vidmem  # noqa
+from _dev import maybe_dev; maybe_dev()   # TOOLS_DEV=1: the developer library (VIDMEM_* switches)
 from vidmem import specs, synthetic as syn
 from vidmem.encoder import FrameEncoder
 arch = sys.argv[1] if len(sys.argv) > 1 else "vit_b16_224"
@@ -10,6 +11,8 @@ dtype = sys.argv[2] if len(sys.argv) > 2 else "f16"
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 441
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 spec = specs.SPECS[arch]
+if len(sys.argv) > 5:
+    spec = dict(spec, layers=int(sys.argv[5]))
 enc = FrameEncoder(spec, syn.encoder_weights(spec, seed=42), dtype=dtype, device=0)
 g = torch.Generator(device="cuda").manual_seed(1)
 S = spec["image"]

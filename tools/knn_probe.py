@@ -2,6 +2,7 @@
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, vidmem
+from _dev import maybe_dev; maybe_dev()
 from vidmem.memory import EmbeddingMemory
 D = int(sys.argv[1]) if len(sys.argv) > 1 else 768
 dt = sys.argv[2] if len(sys.argv) > 2 else "f16"
@@ -13,7 +14,8 @@ g = torch.Generator(device="cuda").manual_seed(7)
 for lo in range(0, M, 250_000):
     n = min(250_000, M - lo)
     x = torch.randn((n, D), generator=g, device="cuda"); mem.append((x / x.norm(dim=1, keepdim=True)).to(td))
-for Q in (16, 64, 256):
+QS = [int(x) for x in sys.argv[5].split(',')] if len(sys.argv) > 5 else [16, 64, 256]
+for Q in QS:
     q = torch.randn((Q, D), generator=g, device="cuda").to(td)
     for _ in range(3): mem.topk(q, k)
     torch.cuda.synchronize(); mem.ctx.profile_enable(512)
