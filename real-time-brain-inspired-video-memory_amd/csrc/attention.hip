@@ -329,6 +329,9 @@ __device__ __forceinline__ void attend_tile_pass2(const char *kl, const char *vl
 // ABL (developer library only, VIDMEM_ATTN_ABL): COMPILE-TIME ablations of the walk - 1 no exponentials, 2 no P.V MFMAs,
 // 4 no K/V fill (kernel), 8 no Q.K MFMAs, 16 no V fragment reads, 32 no K fragment reads.  (A first probe with RUNTIME
 // switches perturbed the kernel by 20 % with every switch off)  Results are garbage under any of them.
+// ABL (developer library only, VIDMEM_ATTN_ABL): COMPILE-TIME ablations of the walk - 1 no exponentials, 2 no P.V MFMAs,
+// 4 no K/V fill (kernel), 8 no Q.K MFMAs, 16 no V fragment reads, 32 no K fragment reads.  (A first probe with RUNTIME
+// switches perturbed the kernel by 20 % with every switch off)  Results are garbage under any of them.
 // s_waitcnt vmcnt(n) for a wave-uniform n known only at run time (the count field is an immediate)
 __device__ __forceinline__ void wait_vmcnt_dyn(int n) {
 #define VM_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
@@ -342,18 +345,11 @@ __device__ __forceinline__ void wait_vmcnt_dyn(int n) {
 #undef VM_W
 }
 
-// The K / V fill of a workgroup arrives in chunks of PAIR_CH_STEPS 32-key steps, issued by the workgroup's LOADER waves
-// (attention_pair_kernel); the other waves' FIRST walk meets the loaders at one barrier per chunk, right before the
-// first step that reads the chunk, so the walk overlaps the rest of the fill.
-constexpr int PAIR_CH_STEPS = 5;
-constexpr int PAIR_MAX_CH = 8;
-
 template <int DT, int NT, bool EXACT, int ABL = 0>
 __device__ __forceinline__ void attend_pair_online(const char *kl, const char *vl,
                                                    const typename vm_elem<DT>::vec8 (&qa)[2],
                                                    const typename vm_elem<DT>::vec8 (&qb)[2], int T, int lane,
-                                                   const bool (&qvalid)[2], uint16_t *const (&dst_row)[2],
-                                                   bool chunk_barriers = false) {
+                                                   const bool (&qvalid)[2], uint16_t *const (&dst_row)[2]) {
     using E = vm_elem<DT>;
     using vec8 = typename E::vec8;
     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -512,20 +508,11 @@ __device__ __forceinline__ void attend_pair_online(const char *kl, const char *v
         }
     };
     constexpr int FULL_STEPS = EXACT ? (NT - 1) / 2 : 0;
-    auto chunk_sync = [&](int ks) {   // first walk of a non-loader wave only; wave-uniform
-        if (chunk_barriers && ks % PAIR_CH_STEPS == 0) __builtin_amdgcn_s_barrier();
-    };
     int ks = 0;
 #pragma unroll 1
-    for (; ks < FULL_STEPS; ++ks) {
-        chunk_sync(ks);
-        step(ks, false, true, false);
-    }
+    for (; ks < FULL_STEPS; ++ks) step(ks, false, true, false);
 #pragma unroll 1
-    for (; ks < NS; ++ks) {
-        chunk_sync(ks);
-        step(ks, true, 2 * ks + 1 < NT, true);
-    }
+    for (; ks < NS; ++ks) step(ks, true, 2 * ks + 1 < NT, true);
 
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -574,62 +561,34 @@ __global__ void __launch_bounds__(NW * 64, 1)
         q1 = __builtin_bit_cast(vec8, *reinterpret_cast<const uint4 *>(qp + 32 + 8 * h));
     };
     const int srow = lane >> 3, scp = lane & 7;
-    // The fill: K and V rows by LDS-DMA (8 rows x 128 B per instruction), in CHUNKS of PAIR_CH_STEPS 32-key steps - chunk
-    // c = the K rows, then the V rows of steps [5c, 5c + 5).  It was 25 % of the kernel with nothing to overlap it (the
-    // whole workgroup waited for all of it; compile-time ablation table: DESIGN.md 4.3).  Now the LAST NL waves - with
-    // 19 pairs over 12 waves the ones that walk one pair where the others walk two - issue every unit up front and then
-    // retire chunk after chunk (counted vmcnt + the workgroup's barrier); the other waves start walking after chunk 0
-    // and meet the loaders at one barrier per chunk (attend_pair_online).  Why dedicated waves: hipcc puts an
-    // s_waitcnt vmcnt(0) in front of the first LDS read it sees while an LDS-DMA OF THE SAME WAVE may be in flight; a
-    // wave that issued none pays nothing for it.
-    constexpr int NS = (NT + 1) / 2;
-    constexpr int NCH = (NS + PAIR_CH_STEPS - 1) / PAIR_CH_STEPS;
-    static_assert(NCH <= PAIR_MAX_CH, "more fill chunks than the walk's barrier schedule knows");
-    constexpr int NL = NW >= 10 ? 5 : 3;
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const bool loader = wave_u >= NW - NL;
+    auto stage = [&](int part, char *dst) {  // rows past T re-read row T-1 (masked / P = 0 later)
+        const char *src = reinterpret_cast<const char *>(block(part));
+#pragma unroll 4
+        for (int grp = wave; grp < ROWS / 8; grp += NW) {
+            int key = grp * 8 + srow;
+            key = key > T - 1 ? T - 1 : key;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + (size_t)key * 128 + ((scp ^ srow) << 4)),
+                                             (lds_ptr_t)(dst + grp * 1024), 16, 0, 2);  // nt: read once
+        }
+    };
+    // The fill is 25 % of this kernel with nothing to overlap it (compile-time ablation table).  Round 4
+    // tried to hide it: the K / V rows in four chunks issued by five loader waves (the ones that walk one pair where
+    // the others walk two), the other waves starting after chunk 0 and meeting the loaders at one barrier per chunk.
+    // Bit-identical, and 7-9 % SLOWER (CLIP-L/14-336, 224 frames: 24.0 -> 26.3 ms of attention per two passes): the
+    // chunk barriers keep the seven walking waves in lockstep and the loaders' own walk starts no earlier than before.
+    // The whole-fill barrier stays (tools/experiments/attention_pair_chunked_fill.patch).
     const int npairs = (qt_lim + 1) / 2;
     vec8 qa[2], qb[2];
-    if (wave < npairs) {   // before the fill: older than every LDS-DMA in this wave's in-order stream
+    if (wave < npairs) {
         load_q(2 * wave, qa[0], qb[0]);
         load_q(2 * wave + 1, qa[1], qb[1]);
     }
-    if (loader) {
-        const char *srck = reinterpret_cast<const char *>(block(1));
-        const char *srcv = reinterpret_cast<const char *>(block(2));
-        int cum[PAIR_MAX_CH];   // units this wave has issued up to and including chunk c
-        int mine = 0, u = 0;
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const int g0 = c * PAIR_CH_STEPS * 4;
-            const int g1 = (c + 1) * PAIR_CH_STEPS * 4 < ROWS / 8 ? (c + 1) * PAIR_CH_STEPS * 4 : ROWS / 8;
-#pragma unroll
-            for (int part = 0; part < 2; ++part) {
-                for (int grp = g0; grp < g1; ++grp, ++u) {
-                    if (u % NL != wave_u - (NW - NL) || (ABL & 4)) continue;
-                    int key = grp * 8 + srow;
-                    key = key > T - 1 ? T - 1 : key;   // rows past T re-read row T-1 (masked / P = 0 later)
-                    __builtin_amdgcn_global_load_lds(
-                        (gbl_ptr_t)((part ? srcv : srck) + (size_t)key * 128 + ((scp ^ srow) << 4)),
-                        (lds_ptr_t)((part ? vl : kl) + grp * 1024), 16, 0, 2);  // nt: read once
-                    ++mine;
-                }
-            }
-            cum[c] = mine;
-        }
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {   // everything of this wave's up to chunk c has landed -> tell the workgroup
-            wait_vmcnt_dyn(mine - cum[c]);
-            __builtin_amdgcn_s_barrier();
-        }
-        // a wait the COMPILER sees (free: everything has landed): without it, it assumes LDS-DMA in flight at the walks'
-        // first LDS read - for every wave, the branch being dynamic - and drains the next pair's query prefetch there
-        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
-    } else if (wave_u >= npairs) {   // no query tile of its own: still a partner in the fill's barriers
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) __builtin_amdgcn_s_barrier();
+    if (!(ABL & 4)) {
+        stage(1, kl);
+        stage(2, vl);
     }
-    bool first = !loader;   // a loader's walks start behind the whole fill
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     for (int pr = wave; pr < npairs; pr += NW) {
         bool qvalid[2];
         uint16_t *dst[2];
@@ -645,8 +604,7 @@ __global__ void __launch_bounds__(NW * 64, 1)
             load_q(2 * (pr + NW), qa[0], qb[0]);
             load_q(2 * (pr + NW) + 1, qa[1], qb[1]);
         }
-        attend_pair_online<DT, NT, EXACT, ABL>(kl, vl, ca, cb, T, lane, qvalid, dst, first);
-        first = false;
+        attend_pair_online<DT, NT, EXACT, ABL>(kl, vl, ca, cb, T, lane, qvalid, dst);
     }
 }
 

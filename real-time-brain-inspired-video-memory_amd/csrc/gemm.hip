@@ -715,8 +715,12 @@ __global__ void __launch_bounds__(512, 1) gemm256p_kernel(GemmArgs g) {
     // panels share an XCD's L2 and stay in phase) was meant to spread that burst: 0 / 50 / 100 / 200 / 400 % of that
     // stagger gave 954 / 956 / 962 / 971 / 981 us on FC1 and lost on every other shape (projection 239 -> 259 us at
     // 100 %): the stores' cost is not the lockstep burst.
-    if (g.dephase_ticks > 0) {
-        const unsigned long long wait = (unsigned long long)(blockIdx.x & 7) * g.dephase_ticks;   // 100 MHz ticks
+    if (g.dephase_ticks != 0) {
+        // > 0: per XCD slot; < 0: a ramp INSIDE every XCD, -ticks per renumbered workgroup (neighbours - which share
+        // operand panels - stay within a fraction of a microsecond of each other, the XCD's 32 bursts spread out)
+        const unsigned long long wait = g.dephase_ticks > 0
+                                            ? (unsigned long long)(blockIdx.x & 7) * g.dephase_ticks
+                                            : (unsigned long long)(vbid % ((int)gridDim.x >> 3 ? (int)gridDim.x >> 3 : 1)) * (-g.dephase_ticks);
         const unsigned long long t_start = wall_clock64();
         while (wall_clock64() - t_start < wait) __builtin_amdgcn_s_sleep(16);
     }
@@ -827,7 +831,10 @@ __global__ void __launch_bounds__(512, 1) gemm256p_kernel(GemmArgs g) {
                 VM_WAIT_EP(4);   // retire Wa0 + Xb0 of K-tile 1; younger: its Xb1, Wa1 (4) [+ stores]
             } else if (more) {
                 stage_Wa1(skt, nb);
-                wait_vmcnt<4>();  // from K-tile 1 on this also retires the epilogue's stores (>= 2 K-tiles old)
+                // from K-tile 1 on this also retires the epilogue's stores (>= 2 K-tiles old).  They cannot be given
+                // longer: the count is in issue order, so waiting for K-tile 2's data - staged BEHIND the stores - waits
+                // for the stores too, and only two K-tiles fit in front of them (two LDS buffers)
+                wait_vmcnt<4>();
                 if (k1_after) ep = 0;
             }
             VM_BAR();
@@ -1114,6 +1121,8 @@ int vm_gemm(vm_ctx *ctx, int dtype, const GemmArgs &g, int epi, hipStream_t st) 
         const double tile_us = 2.0 * 256 * 256 * g.K / 3.4e6;
         const double rounds = (double)((g.M + 255) / 256) * (g.N / 256) / (ctx ? ctx->num_cus : 256);
         a.dephase_ticks = (pct > 0 && rounds >= 4.0) ? (int)(tile_us * 100.0 / 8.0 * pct / 100.0) : 0;
+        static const long ramp = VM_DEV_ENV("GEMM_DEPHASE_RAMP", 0);   // 100 MHz ticks per workgroup inside an XCD
+        if (ramp > 0 && rounds >= 4.0) a.dephase_ticks = -(int)ramp;
     }
     if (epi == EPI_GELU16 && !a.gelu_tab) return vm_fail(ctx, VM_ERR_INVALID, "vm_gemm: GELU epilogue needs a context");
     {   // feature-tile groups of the persistent 256 x 256 kernel (gemm256p_kernel, "Tile order")
