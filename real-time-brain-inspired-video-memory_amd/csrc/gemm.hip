@@ -231,6 +231,12 @@ __device__ __forceinline__ void epilogue_row(const GemmArgs &g, const f32x4 (&a)
 // ---------------------------------------------------------------------------------------------------------------
 // 16-bit epilogue of the persistent kernel: bias (+ activation), pack, wave-private LDS transpose, stores of
 // 4 token rows x 256 contiguous bytes.  acc[i][p][e] = out[token tbase + 16 p + r16][feature fw + 16 i + 4 h + e].
+// Why through LDS (round 4, tools/store_probe.hip): a CU's store path takes a 16-byte-per-lane store at full rate only
+// when CONSECUTIVE LANES write consecutive addresses (4 rows x 256 B per instruction: 128 KiB in 2,350 ticks alone on
+// the chip); 16 rows x 64 B and 8 rows x 128 B - what lane-row exchanges (v_permlane16_swap + DPP row_ror:8) can build
+// from the MFMA layout without LDS, bit-identical outputs - take 9,050 ticks, and the GEMM with them was 0-8 % slower
+// (tools/experiments/gemm_epilogue_lane_swap_and_store_policy.patch).  Cache policy of these stores: nt = sc1 nt <
+// plain = sc0 < sc1 = sc0 sc1 (same patch; QKV 682 / 684 / 724 / 725 / 722 / 723 us).
 //
 // Its LDS traffic (bias table, transpose scratch) is issued by INLINE ASM.  Written as plain C++ accesses, hipcc
 // puts an s_waitcnt vmcnt(0) in front of the first of them: with LDS-DMA in flight it cannot prove that the access
@@ -847,6 +853,9 @@ __global__ void __launch_bounds__(512, 1) gemm256p_kernel(GemmArgs g) {
         // (their LDS round trips and store issue overlap instead of serialising); wave row 1 takes its matching extra
         // barrier after the epilogue, which also restores the one-barrier offset for the next tile.
         if (wr == 0) VM_BAR();
+#ifdef VM_GEMM_ABLATE
+        if (g.stamps && tid == 0 && tcount < 64) g.stamps[((size_t)blockIdx.x * 64 + tcount) * 2] = wall_clock64();
+#endif
         // the consumed buffer is free (every wave's reads of it retired before this barrier): stage K-tile 1 of the
         // next tile into it NOW, ahead of the epilogue's stores in this CU's in-order memory pipe
         const bool do_prestage = has_next && nk >= 2;
@@ -889,6 +898,9 @@ __global__ void __launch_bounds__(512, 1) gemm256p_kernel(GemmArgs g) {
             }
         }
         if (wr == 1) VM_BAR();
+#ifdef VM_GEMM_ABLATE
+        if (g.stamps && tid == 0 && tcount < 64) g.stamps[((size_t)blockIdx.x * 64 + tcount) * 2 + 1] = wall_clock64();
+#endif
         ++tcount;
         if (!has_next) break;
         {   // how many stores did this wave's epilogue leave in the pipe?  exact only for a full 16-bit tile

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <vector>
 #include <cmath>
+#include <algorithm>
 #include "../real-time-brain-inspired-video-memory_amd/csrc/vm_kernels.h"
 void vm_gemm_set_variant(int v);
 
@@ -88,6 +89,23 @@ int main(int argc, char **argv) {
         for (int i = 0; i < iters; ++i) vm_gemm(ctx, VM_F16, g, epi, 0);
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
+        if (getenv("STAMPS") && variant == 3) {   // tile-boundary wall-clock stamps of one more launch: how far apart do the CUs run?
+            unsigned long long *ds; CK(hipMalloc(&ds, 256 * 64 * 2 * 8)); CK(hipMemset(ds, 0, 256 * 64 * 2 * 8));
+            GemmArgs gs = g; gs.stamps = ds;
+            vm_gemm(ctx, VM_F16, gs, epi, 0); CK(hipDeviceSynchronize());
+            std::vector<unsigned long long> hs(256 * 64 * 2); CK(hipMemcpy(hs.data(), ds, hs.size() * 8, hipMemcpyDeviceToHost));
+            unsigned long long t0 = ~0ull; for (int b = 0; b < 256; ++b) if (hs[b * 128] && hs[b * 128] < t0) t0 = hs[b * 128];
+            // per round: spread of the "K loop done" stamps over the CUs (min / median / max, us after the first CU's first
+            // boundary), the same within XCD 0 (blockIdx % 8 == 0), and the median epilogue duration (stamp 1 - stamp 0)
+            for (int r = 0; r < 64; r += (r < 4 ? 1 : 4)) {
+                std::vector<double> a, x0, ep;
+                for (int b = 0; b < 256; ++b) { const unsigned long long s0 = hs[(b * 64 + r) * 2], s1 = hs[(b * 64 + r) * 2 + 1]; if (!s0 || !s1) continue; a.push_back((s0 - t0) / 100.0); ep.push_back((s1 - s0) / 100.0); if (b % 8 == 0) x0.push_back((s0 - t0) / 100.0); }
+                if (a.size() < 8) break;
+                std::sort(a.begin(), a.end()); std::sort(x0.begin(), x0.end()); std::sort(ep.begin(), ep.end());
+                printf("  round %2d: K-loop-done over %3zu CUs: min %7.2f median %7.2f max %7.2f us (spread %.2f; XCD 0: %.2f); epilogue median %.2f max %.2f us\n", r, a.size(), a.front(), a[a.size() / 2], a.back(), a.back() - a.front(), x0.empty() ? 0.0 : x0.back() - x0.front(), ep[ep.size() / 2], ep.back());
+            }
+            CK(hipFree(ds));
+        }
         printf("M=%d N=%d K=%d epi=%d variant=%s: %.1f us  %.0f TFLOP/s  maxerr %.3g (ref max %.3g) bad=%zu bits-differ=%zu\n", M, N, K, epi,
                variant == 1280 ? "256p default-policy stores" : variant == 1152 ? "256p staggered" : variant == 1056 ? "256p X-panel0" : variant == 1088 ? "256p W-tile0" : variant == 1120 ? "256p X0+W0" : variant == 1136 ? "256p X0+W0 noEPI" : variant == 1 ? "128^2" : (variant == 2 ? "256^2" : variant == 3 ? "256^2 persistent" : (variant == 1032 ? "256p noSTORE" : variant == 1040 ? "256p noEPILOGUE" : variant == 130 ? "256 noSTORE" : variant == 18 ? "256 noDMA" : variant == 34 ? "256 noDSREAD" : variant == 50 ? "256 noDMA noDSREAD" : variant == 66 ? "256 noMFMA" : variant == 82 ? "256 noDMA noMFMA" : "256 none")), ms * 1e3, 2.0 * M * N * K / (ms * 1e-3) / 1e12, maxerr, maxref, bad, diff16);
     }
