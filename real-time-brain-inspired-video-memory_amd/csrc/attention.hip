@@ -608,6 +608,142 @@ __global__ void __launch_bounds__(NW * 64, 1)
     }
 }
 
+// PERSISTENT form of the pair kernel (round 4): one workgroup per CU walks (frame, head) items, and the NEXT item's K / V
+// rows travel HBM -> registers while the current item is still being walked.  With 19 pairs on 12 waves seven waves walk
+// two pairs and five walk one (in the last layer, CLS rows only: one wave walks, eleven have nothing): the waves that
+// are done early hold no live state, so each of them fetches its share of the next item's 148 KB into registers
+// (30 x 16 B per lane for five waves) - plain global loads, no LDS needed while the others still read the current
+// images - and after the barrier that ends the walk writes them to LDS with ds_write_b128 (~0.5 us).  The K / V fill,
+// 25 % of the one-workgroup-per-item kernel with nothing to overlap it (ablation table; a chunked fill
+// by loader waves was 7-9 % slower), leaves the critical path.  Same LDS image (row r at r * 128, 16-byte chunk c
+// holding source chunk c ^ (r & 7), rows past T re-reading row T - 1), same walk: bit-identical outputs.
+// PF_MAX: 16-byte registers a prefetching wave may hold; the launcher picks this kernel only when the idle waves' share
+// fits (pair counts 1-7 and 13-19 with 12 waves).
+template <int DT, int NT, bool EXACT, int NW, int PF_MAX>
+__global__ void __launch_bounds__(NW * 64, 1)
+    attention_pair_persist_kernel(const uint16_t *__restrict__ qkv, uint16_t *__restrict__ ctx_out, int T, int heads,
+                                  int qt_lim, int items) {
+    using E = vm_elem<DT>;
+    using vec8 = typename E::vec8;
+    constexpr int ROWS = NT * 16;
+    constexpr int CHUNKS = 2 * ROWS * 8;   // 16-byte chunks of the K image followed by the V image
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *kl = smem, *vl = smem + (size_t)ROWS * 128;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, h = lane >> 4;
+    const int H = heads * 64;
+    const size_t M = (size_t)(items / heads) * T;
+    if ((int)blockIdx.x >= items) return;
+    auto block = [&](int item, int part) {
+        const int b = item / heads, head = item - b * heads;
+        return qkv + ((size_t)(part * heads + head) * M + (size_t)b * T) * 64;
+    };
+    auto load_q = [&](int item, int qt, vec8 &q0, vec8 &q1) {
+        int qtok = qt * 16 + r16;
+        if (qtok > T - 1) qtok = T - 1;
+        const uint16_t *qp = block(item, 0) + (size_t)qtok * 64;
+        q0 = __builtin_bit_cast(vec8, *reinterpret_cast<const uint4 *>(qp + 8 * h));
+        q1 = __builtin_bit_cast(vec8, *reinterpret_cast<const uint4 *>(qp + 32 + 8 * h));
+    };
+    const int npairs = (qt_lim + 1) / 2;
+    const int maxc = (npairs + NW - 1) / NW;                 // pairs of the busiest wave
+    int w0 = npairs - (maxc - 1) * NW;                       // first wave with fewer pairs than that
+    if (w0 >= NW) w0 = 0;                                    // none: every wave fetches after its walk (no overlap)
+    const int P = NW - w0, pw = wave - w0;                   // prefetching waves, this wave's rank among them
+    // (PF_MAX * P >= CHUNKS / 64: checked by the launcher)
+
+    int item = blockIdx.x;
+    vec8 qa[2], qb[2];
+    if (wave < npairs) {
+        load_q(item, 2 * wave, qa[0], qb[0]);
+        load_q(item, 2 * wave + 1, qa[1], qb[1]);
+    }
+    {   // first item: LDS-DMA fill by every wave, as in the one-item kernel
+        const int srow = lane >> 3, scp = lane & 7;
+#pragma unroll
+        for (int part = 1; part <= 2; ++part) {
+            const char *src = reinterpret_cast<const char *>(block(item, part));
+            char *dst = part == 1 ? kl : vl;
+#pragma unroll 4
+            for (int grp = wave; grp < ROWS / 8; grp += NW) {
+                int key = grp * 8 + srow;
+                key = key > T - 1 ? T - 1 : key;
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + (size_t)key * 128 + ((scp ^ srow) << 4)),
+                                                 (lds_ptr_t)(dst + grp * 1024), 16, 0, 2);  // nt: read once
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    while (true) {
+        const int next = item + (int)gridDim.x;
+        const bool has_next = next < items;
+        const int b = item / heads, head = item - b * heads;
+        for (int pr = wave; pr < npairs; pr += NW) {
+            bool qvalid[2];
+            uint16_t *dst[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int qt = 2 * pr + t;
+                const int qtok = qt * 16 + r16;
+                qvalid[t] = qt < qt_lim && qtok < T;
+                dst[t] = ctx_out + ((size_t)b * T + (qvalid[t] ? qtok : 0)) * H + head * 64;
+            }
+            const vec8 ca[2] = {qa[0], qa[1]}, cb[2] = {qb[0], qb[1]};
+            if (pr + NW < npairs) {            // this wave's next pair of the same item ...
+                load_q(item, 2 * (pr + NW), qa[0], qb[0]);
+                load_q(item, 2 * (pr + NW) + 1, qa[1], qb[1]);
+            } else if (has_next && pw < 0) {   // ... or its first pair of the next item: in flight during this walk
+                load_q(next, 2 * wave, qa[0], qb[0]);   // (a prefetching wave loads it behind its LDS writes instead:
+                load_q(next, 2 * wave + 1, qa[1], qb[1]);   // 16 registers it needs for the rows, latency it can afford)
+            }
+            attend_pair_online<DT, NT, EXACT, 0>(kl, vl, ca, cb, T, lane, qvalid, dst);
+        }
+        if (!has_next) break;
+        // the waves that are done early fetch the next item's rows into registers while the others still walk.  A wave
+        // instruction moves one 8-row group g of the combined K | V image (1 KiB): which image, and the group's first
+        // row, are wave-uniform; per lane only the row inside the group and its swizzled chunk (both fixed).
+        // Two barriers either way: (1) every wave's reads of the current images have returned (their MFMAs consumed
+        // them) - raw s_barrier, no vmcnt wait for the walkers' context stores; (2) the new images are in LDS.
+        if (pw >= 0) {
+            typedef unsigned pf_u32x4 __attribute__((ext_vector_type(4)));
+            pf_u32x4 buf[PF_MAX];
+            const char *kbase = reinterpret_cast<const char *>(block(next, 1));
+            const char *vbase = reinterpret_cast<const char *>(block(next, 2));
+            int lrow = lane >> 3;
+            asm volatile("" : "+v"(lrow));   // opaque per item: keeps hoisted offsets from living across the walk
+            const unsigned lane_term = (unsigned)(((lane & 7) ^ lrow) << 4);
+#pragma unroll
+            for (int j = 0; j < PF_MAX; ++j) {   // straight-line: under per-j branches the compiler keeps buf in scratch
+                int g = __builtin_amdgcn_readfirstlane(j * P + pw);
+                g = g < CHUNKS / 64 ? g : CHUNKS / 64 - 1;   // past the end: the last group again (same bytes, same place)
+                const bool is_v = g >= ROWS / 8;
+                int key = (is_v ? g - ROWS / 8 : g) * 8 + lrow;
+                key = key > T - 1 ? T - 1 : key;
+                const char *src = (is_v ? vbase : kbase) + ((unsigned)key * 128u + lane_term);
+                buf[j] = __builtin_nontemporal_load(reinterpret_cast<const pf_u32x4 *>(src));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < PF_MAX; ++j) {
+                int g = __builtin_amdgcn_readfirstlane(j * P + pw);
+                g = g < CHUNKS / 64 ? g : CHUNKS / 64 - 1;
+                *reinterpret_cast<pf_u32x4 *>(smem + (size_t)g * 1024 + lane * 16) = buf[j];
+            }
+            if (wave < npairs) {
+                load_q(next, 2 * wave, qa[0], qb[0]);
+                load_q(next, 2 * wave + 1, qa[1], qb[1]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        item = next;
+    }
+}
+
 // One workgroup of NW waves per (frame, head): K rows by LDS-DMA, barrier; the V rows' LDS-DMA is issued next and
 // lands while every wave runs pass 1 of its first query tile; then tiles wave, wave + NW, ...
 template <int DT, int NT, bool EXACT, int NW, bool ONLINE>
@@ -701,7 +837,30 @@ int launch_long(vm_ctx *ctx, const uint16_t *qkv, uint16_t *out, int B, int T, i
         }
 #undef VM_PAIR_ABL
 #endif
-        if (pair_env == 8) VM_PAIR_GO(8)
+        // persistent walk with the next item's rows prefetched into the idle waves' registers: when their share fits
+        static const int persist_env = (int)VM_DEV_ENV("ATTN_PERSIST", 1);
+        const int npairs = (ql + 1) / 2, maxc = (npairs + 11) / 12;
+        int w0 = npairs - (maxc - 1) * 12;
+        if (w0 >= 12) w0 = 0;
+        constexpr int GROUPS = 2 * NT * 16 / 8;             // 8-row groups of the K | V image
+        constexpr int PF_FEW = (GROUPS + 4) / 5;            // 16-byte registers per lane with five prefetching waves
+        constexpr int PF_MANY = (GROUPS + 10) / 11;         // ... with eleven (one pair to walk: the last layer's CLS rows)
+        const int pf = (GROUPS + (12 - w0) - 1) / (12 - w0);
+        const int items = B * heads;
+#define VM_PERSIST_GO(PF)                                                                                            \
+    {                                                                                                                \
+        auto kern = attention_pair_persist_kernel<DT, NT, EXACT, 12, PF>;                                            \
+        static unsigned long long attr_set = 0; /* one bit per device */                                              \
+        if (!((attr_set >> (ctx->device & 63)) & 1ull)) {                                                            \
+            VM_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            attr_set |= 1ull << (ctx->device & 63);                                                                  \
+        }                                                                                                            \
+        kern<<<items < ctx->num_cus ? items : ctx->num_cus, 12 * 64, lds, st>>>(qkv, out, T, heads, ql, items);      \
+    }
+        if (persist_env && pair_env == 12 && pf <= PF_MANY) VM_PERSIST_GO(PF_MANY)
+        else if (persist_env && pair_env == 12 && pf <= PF_FEW) VM_PERSIST_GO(PF_FEW)
+#undef VM_PERSIST_GO
+        else if (pair_env == 8) VM_PAIR_GO(8)
         else if (pair_env == 10) VM_PAIR_GO(10)
         else VM_PAIR_GO(12)
 #undef VM_PAIR_GO

@@ -330,10 +330,13 @@ def test_bench_size_batches_take_the_big_kernels_and_agree(name, dtype, n):
 
 
 def test_long_attention_variants_agree(tmp_path):
-    """The 577-token attention has three builds (csrc/attention.hip): two query tiles per walk with a lazily raised
-    softmax reference (what the release library runs), one tile per walk (VIDMEM_ATTN_PAIR=0), and the two-pass softmax
-    against the exact row maximum (VIDMEM_ATTN_ONLINE=0).  Same softmax in all three: the embeddings may differ by the
-    rounding of the 16-bit probabilities only.  The two other builds are reachable only in the DEVELOPER library
+    """The 577-token attention has four builds (csrc/attention.hip): two query tiles per walk with a lazily raised
+    softmax reference, as a PERSISTENT workgroup per CU whose idle waves fetch the next (frame, head)'s K / V rows into
+    registers during the walk (what the release library runs); the same walk with one workgroup per item and an LDS-DMA
+    fill (VIDMEM_ATTN_PERSIST=0) - identical bits required, on a batch that gives some CUs two items and in both the
+    all-rows and the CLS-rows-only layer; one tile per walk (VIDMEM_ATTN_PAIR=0); and the two-pass softmax
+    against the exact row maximum (VIDMEM_ATTN_ONLINE=0).  Same softmax in all of them: the embeddings may differ by the
+    rounding of the 16-bit probabilities only.  The other builds are reachable only in the DEVELOPER library
     (make -C csrc dev: -DVM_DEV_SWITCHES; the release library reads no environment variable), where the switches are
     read once per process, hence one child process per variant; skipped when that library has not been built."""
     import subprocess
@@ -353,16 +356,18 @@ spec = dict(arch="t", image=336, patch=14, hidden=256, layers=2, heads=4, mlp=51
             pre_ln=True, patch_bias=False, proj_dim=0, mean=(0.5,) * 3, std=(0.5,) * 3)
 enc = FrameEncoder(spec, syn.encoder_weights(spec, seed=3, std=0.05), "f16")
 assert enc.tokens == 577
-px = syn.normal(77, "px", (3, 3, 336, 336))
+px = syn.normal(77, "px", (70, 3, 336, 336))     # 70 frames x 4 heads = 280 items > the CUs of the device
 np.save(sys.argv[2], enc.encode_patches(enc.patches_from_pixels(torch.from_numpy(px))).float().cpu().numpy())
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = {}
-    for name, env in (("pair", {}), ("single", {"VIDMEM_ATTN_PAIR": "0"}), ("two_pass", {"VIDMEM_ATTN_ONLINE": "0"})):
+    for name, env in (("pair", {}), ("one_item", {"VIDMEM_ATTN_PERSIST": "0"}), ("single", {"VIDMEM_ATTN_PAIR": "0"}),
+                      ("two_pass", {"VIDMEM_ATTN_ONLINE": "0"})):
         path = str(tmp_path / f"{name}.npy")
         subprocess.check_call([sys.executable, "-c", prog, root, path], env=dict(os.environ, **env))
         outs[name] = np.load(path)
     assert np.isfinite(outs["pair"]).all()
+    assert np.array_equal(outs["one_item"], outs["pair"]), rel(outs["one_item"], outs["pair"])
     for name in ("single", "two_pass"):
         d = rel(outs[name], outs["pair"])
         print(f"{name} vs pair: {d:.2e}")
