@@ -51,7 +51,7 @@ __device__ __forceinline__ void list_insert(float (&ls)[KL], int (&lo)[KL], floa
 // scan
 // ---------------------------------------------------------------------------------------------------------
 // LDS: [QT*16][D] query elements (chunk-swizzled); reused afterwards as the merge area [waves][QT*16][KL] {f32,i32}.
-template <int DT, int KL, int QT>
+template <int DT, int KL, int QT, int LBV = 8>   // LBV: 16-byte row loads per lane and batch (see LB below)
 __global__ void __launch_bounds__(SCAN_THREADS)
     topk_scan_kernel(const uint16_t *__restrict__ mem, const float *__restrict__ rnorm,
                      const uint16_t *__restrict__ queries, const int64_t *__restrict__ d_total, int64_t cap,
@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(SCAN_THREADS)
     // of this row tile or of the wave's next one - is issued before the MFMAs of the current batch: with two waves per
     // SIMD (the per-lane lists fill the register file) nothing else hides the HBM latency, and without the prefetch
     // a multi-tile scan spent ~9 us per row tile waiting for three round trips.
-    constexpr int LB = 8;
+    constexpr int LB = LBV;
     const int64_t tile_step = (int64_t)nbx * nw;
     const uint4 *qrow = qlds + r16 * chunks;  // this lane's query row of tile 0
     const int tstride = 16 * chunks;          // uint4 units between query tiles
@@ -730,6 +730,13 @@ template <int DT, int KL, int QT>
 int launch_scan(vm_memory *m, const ScanPlan &p, int nblk, int64_t row_limit, const float *thr_s, const int *thr_o,
                 const void *queries, int Q, float *part_s, int *part_o, hipStream_t st) {
     auto kern = topk_scan_kernel<DT, KL, QT>;
+#ifdef VM_DEV_SWITCHES   // developer A/B (VIDMEM_SCAN_LB = 12 | 24): row loads per batch of the one-tile f16 scan
+    if constexpr (QT == 1 && KL == 16 && DT == VM_F16) {
+        static const int lb_env = (int)VM_DEV_ENV("SCAN_LB", 8);
+        if (lb_env == 12) kern = topk_scan_kernel<DT, KL, QT, 12>;
+        if (lb_env == 24) kern = topk_scan_kernel<DT, KL, QT, 24>;
+    }
+#endif
     if (p.lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)p.lds);
