@@ -487,8 +487,9 @@ extern "C" int vm_encoder_create(vm_ctx *ctx, const vm_encoder_desc *desc, const
     e->patch_k = round_up(3 * d.patch * d.patch, 64);
     e->out_dim = d.proj_dim ? d.proj_dim : d.hidden;
     if (e->tokens > 592) {
+        const int tokens = e->tokens;
         delete e;
-        return vm_fail(ctx, VM_ERR_UNSUPPORTED, "%d tokens per frame > 592", e->tokens);
+        return vm_fail(ctx, VM_ERR_UNSUPPORTED, "%d tokens per frame > 592", tokens);
     }
     e->micro_batch = 0;
     e->cls_last = 3;

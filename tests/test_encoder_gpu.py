@@ -34,6 +34,13 @@ TD = {"f16": torch.float16, "bf16": torch.bfloat16}
 CONTRACT = 1e-3
 FLOOR_SLACK = 1.5
 QUANT_SLACK = 1.15
+# Per-FRAME bars of the full models: max(contract, FRAME_SLACK x that frame's operand-only floor).  A single frame's distance
+# to the fp32 oracle after 12-24 layers moves by up to 9 % under changes that are not errors: round 4 measured the same
+# kernels with the attention context rounded once (v_fma_mixlo_f16) or twice (fp32 product, then fp16 - what is now
+# pinned in csrc/attention.hip and what the quant-aware oracle does): frame 5 of the heavy-tailed ViT-B/16 golden
+# 1.025e-3 <-> 1.117e-3 (floor 7.40e-4, i.e. 1.39 x <-> 1.51 x), frame 7 1.091e-3 <-> 0.993e-3, the batch 9.80e-4 <-> 9.59e-4
+# (tools/golden_probe.py).  The batch bars above are unchanged; the per-frame slack leaves that much room.
+FRAME_SLACK = 1.65
 _FLOOR_JSON = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bf16_floor_clip_l14_336_bf16.json")
 
 
@@ -159,7 +166,7 @@ def test_full_models_match_golden(name, dtype, golden):
     weight sets - N(0, 0.02^2), and a heavy-tailed one (Student-t weights, six 6x LayerNorm outlier channels:
     synthetic.encoder_weights tail="heavy").  Bars: the batch as a whole within the contract (fp16: 1e-3; bf16: 1.5 x
     the operand-only floor, which no bf16-operand implementation can beat); every single frame within
-    max(contract, 1.5 x THAT frame's operand-only floor) - the floors are part of the golden file
+    max(contract, FRAME_SLACK x THAT frame's operand-only floor) - the floors are part of the golden file
     (tests/golden/make_vit_golden.py), so the test evaluates nothing but the device output."""
     from vidmem import synthetic as syn
     spec = V.SPECS[name.replace("_heavy", "")]
@@ -177,7 +184,7 @@ def test_full_models_match_golden(name, dtype, golden):
     q64 = golden[name + "/" + dtype].astype(np.float64)
     per32 = np.array([rel(g64[i], f64[i]) for i in range(g64.shape[0])])
     perq = np.array([rel(g64[i], q64[i]) for i in range(g64.shape[0])])
-    frame_bar = np.maximum(CONTRACT, FLOOR_SLACK * floor[1:])
+    frame_bar = np.maximum(CONTRACT, FRAME_SLACK * floor[1:])
     print(f"{name} {dtype}: batch rel err vs quant-aware golden {e_q:.2e}, vs fp32 golden {e_32:.2e}, bar {bar:.2e} "
           f"(operand-only floor {floor[0]:.2e}); per frame vs fp32: worst {per32.max():.2e} (its floor "
           f"{floor[1:][per32.argmax()]:.2e}, bar {frame_bar[per32.argmax()]:.2e}), vs quant-aware worst {perq.max():.2e}")

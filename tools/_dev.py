@@ -4,6 +4,9 @@ import os
 
 
 def maybe_dev():
-    if os.environ.get("TOOLS_DEV"):
+    if os.environ.get("TOOLS_LIB"):      # any other build of the library (an older commit's, for a bisection)
+        from vidmem import _lib
+        _lib.LIB_PATH = os.path.abspath(os.environ["TOOLS_LIB"])
+    elif os.environ.get("TOOLS_DEV"):
         from vidmem import _lib
         _lib.use_dev_library()
