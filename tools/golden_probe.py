@@ -24,6 +24,6 @@ for rep in range(2):
     got = enc.encode_patches(enc.patches_from_pixels(torch.from_numpy(px))).float().cpu().numpy()
     g64, f64 = got.astype(np.float64), golden[name + "/fp32"].astype(np.float64)
     per32 = np.array([rel(g64[i], f64[i]) for i in range(g64.shape[0])])
-    print(f"{name} {dtype} rep {rep}: batch {rel(got, golden[name + '/fp32']):.4e}; per frame {np.array2string(per32, precision=6)}; "
-          f"bars {np.array2string(np.maximum(1e-3, 1.5 * floor[1:]), precision=6)}; same bits as rep 0: {prev is None or np.array_equal(prev, got)}")
+    print(f"{name} {dtype} rep {rep}: batch {rel(got, golden[name + '/fp32']):.4e} (vs quant-aware {rel(got, golden[name + '/' + dtype]):.4e}, floor {floor[0]:.3e}); floors per frame {np.array2string(floor[1:], precision=6)}; per frame {np.array2string(per32, precision=6)}; "
+          f"bars {np.array2string(np.maximum(1e-3, 1.65 * floor[1:]), precision=6)}; same bits as rep 0: {prev is None or np.array_equal(prev, got)}")
     prev = got if prev is None else prev
