@@ -47,6 +47,9 @@ def parse():
                          "1,048,576 = BASELINE configs[3], 8 M rows over 8 GPUs, when --gpus > 1)")
     ap.add_argument("--no-extractor", action="store_true", help="skip the plugin-path leg (process_video on a host clip)")
     ap.add_argument("--extractor-frames", type=int, default=4096)
+    ap.add_argument("--extractor-long-frames", type=int, default=16384,
+                    help="frames of the second, longer clip of the plugin-path leg (a 9-minute video at 30 fps; the "
+                         "leg's fixed head and tail weigh less on it); 0 = skip")
     ap.add_argument("--look-ahead-chunks", type=int, default=0,
                     help="chunks per encoder call in the plugin-path leg (0 = auto, the config default: two encoder passes)")
     ap.add_argument("--no-two-stream", action="store_true", help="skip the one-stream A/B beside the main leg")
@@ -680,6 +683,21 @@ def main():
                     dt = time.perf_counter() - t0
                     ext[la] = nfr / dt
                     exm.close()
+                if args.extractor_long_frames > nfr:
+                    # the same class on a longer clip (distinct random frames, kernels warm from the runs above)
+                    nlong = args.extractor_long_frames
+                    clip2 = os.path.join(td, "clip_long.npy")
+                    np.save(clip2, np.random.default_rng(12).integers(0, 256, size=(nlong, 224, 224, 3), dtype=np.uint8))
+                    exm = EmbeddingMemory(R + nlong, D, "f16", ring=False, device=local_rank)
+                    exm.append(mem_rows)
+                    # (cfg of the last run above: the configured look-ahead; its memory section is unused - a memory is passed)
+                    ex = FrameEmbeddingExtractor(cfg, encoder=enc, memory=exm)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    asyncio.run(ex.process_video(clip2, os.path.join(td, "out_long.json")))
+                    torch.cuda.synchronize()
+                    ext["long"] = nlong / (time.perf_counter() - t0)
+                    exm.close()
             finally:
                 os.chdir(cwd)
         out["extractor"] = {
@@ -690,6 +708,12 @@ def main():
             "frames_per_s": ext[args.look_ahead_chunks],
             "fraction_of_value": ext[args.look_ahead_chunks] / value,
         }
+        if "long" in ext:
+            out["extractor"]["long_clip"] = {
+                "frames": args.extractor_long_frames, "frames_per_s": ext["long"], "fraction_of_value": ext["long"] / value,
+                "what": "one process_video run of the same extractor on a longer clip of distinct random frames: the head "
+                        "(first read + staging, ramp of small groups) and the tail (last read-back, JSON + metrics files) "
+                        "are per clip, not per frame"}
 
     # ---- streaming leg (BASELINE configs[4]): 16 x 1080p frames per chunk, rolling 2M-row memory, one hipGraph ------
     if rank == 0 and world == 1 and not args.no_streaming:

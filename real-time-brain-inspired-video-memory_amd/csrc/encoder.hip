@@ -458,7 +458,7 @@ struct vm_encoder {
     // matrix-bound GEMMs of the other; see vm_encode.  AUTO = two streams unless per-kernel timing is on.
     int schedule;
     hipStream_t side[2];
-    hipEvent_t ev_fork, ev_join[2];
+    hipEvent_t ev_fork, ev_join[2], ev_phase;   // ev_phase: developer experiment (start offset of the second stream)
 };
 
 static int round_up(int x, int a) { return (x + a - 1) / a * a; }
@@ -501,6 +501,7 @@ extern "C" int vm_encoder_create(vm_ctx *ctx, const vm_encoder_desc *desc, const
             if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming);
         }
         if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_phase, hipEventDisableTiming);
         if (he != hipSuccess) {
             vm_encoder_destroy(e);   // destroys whatever was created so far
             return vm_fail(ctx, VM_ERR_HIP, "encoder streams: %s", hipGetErrorString(he));
@@ -591,6 +592,7 @@ extern "C" void vm_encoder_destroy(vm_encoder *e) {
         if (e->ev_join[i]) (void)hipEventDestroy(e->ev_join[i]);
     }
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_phase) (void)hipEventDestroy(e->ev_phase);
     if (e->blob) (void)hipFree(e->blob);
     delete[] e->layers;
     delete e;
@@ -841,12 +843,22 @@ extern "C" int vm_encode(vm_encoder *e, const void *patches, int B, void *out_em
             A.rows = A.nb * T;
             A.ws = dual && (pass & 1) ? ws1 : ws0;
             st = dual ? e->side[pass & 1] : st0;    // the stage lambdas launch on `st`
+            // developer experiment (VIDMEM_ENC_PHASE = n, measured null: DESIGN.md 4.6): the second stream starts behind
+            // the n-th stage of the first pass's first layer instead of together with it
+            static const int phase_env = (int)VM_DEV_ENV("ENC_PHASE", 0);
+            const bool mark = dual && phase_env > 0 && pass == 0;
+            if (dual && phase_env > 0 && pass == 1) (void)hipStreamWaitEvent(st, e->ev_phase, 0);
             VM_TRY(embed(A));
             for (int l = 0; l < d.layers; ++l) {
                 VM_TRY(ln1(A, l));
+                if (mark && l == 0 && phase_env == 1) (void)hipEventRecord(e->ev_phase, st);
                 VM_TRY(attn_block(A, l));
+                if (mark && l == 0 && phase_env == 2) (void)hipEventRecord(e->ev_phase, st);
                 VM_TRY(ln2(A, l));
+                if (mark && l == 0 && phase_env == 3) (void)hipEventRecord(e->ev_phase, st);
                 VM_TRY(mlp_block(A, l));
+                if (mark && l == 0 && phase_env == 4) (void)hipEventRecord(e->ev_phase, st);
+                if (mark && l == 1 && phase_env == 5) (void)hipEventRecord(e->ev_phase, st);   // a layer and a half... (after layer 1's MLP)
             }
             VM_TRY(pool(A));
             b0 += A.nb;
