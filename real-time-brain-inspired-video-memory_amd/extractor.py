@@ -261,6 +261,12 @@ class FrameEmbeddingExtractor:
                 groups.append(plan[i:i + size])
                 i += size
                 size = min(L, size * 2)
+            # ... and the last group is a small one (a quarter of L): a group's results are read back and serialised while
+            # the NEXT group runs, so only the last group's share of that work is exposed at the end of a clip
+            tail = max(1, L // 4)
+            if len(groups) >= 2 and len(groups[-1]) > tail + max(1, L // 8):
+                last = groups.pop()
+                groups += [last[:-tail], last[-tail:]]
             dev = self.encoder.device
 
             def read_and_stage(gi):
@@ -298,12 +304,23 @@ class FrameEmbeddingExtractor:
                     group_time = time.perf_counter() - t_start
                 live = [c for c in chunks if c["nframes"]]
                 off = 0
+                # row -> id as EmbeddingMemory.id_of does it, without 10 method calls per frame (the last group's share
+                # of this loop is the tail of every clip: nothing is left to overlap it with)
+                ids_tab, tab_base = getattr(self.memory, "ids", None), getattr(self.memory, "table_base", 0)
+                tab_len = len(ids_tab) if ids_tab is not None else 0
+                id_of = self.memory.id_of       # a memory stand-in without the table (tests): its own lookup
+                all_s = host_s.tolist() if host_s is not None else []
+                all_r = host_r.tolist() if host_r is not None else []
                 for c in live:
                     similar = []
                     if c["searched"]:
                         n = c["nframes"]
-                        for s_row, r_row in zip(host_s[off:off + n].tolist(), host_r[off:off + n].tolist()):
-                            similar.append([(self.memory.id_of(r), float(s)) for s, r in zip(s_row, r_row) if r >= 0])
+                        for s_row, r_row in zip(all_s[off:off + n], all_r[off:off + n]):
+                            if ids_tab is None:
+                                similar.append([(id_of(r), float(s)) for s, r in zip(s_row, r_row) if r >= 0])
+                            else:
+                                similar.append([(ids_tab[r - tab_base] if 0 <= r - tab_base < tab_len else None, s)
+                                                for s, r in zip(s_row, r_row) if r >= 0])
                         off += n
                     chunk_time = group_time / len(live)
                     results.append({
