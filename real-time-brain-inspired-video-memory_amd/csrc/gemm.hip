@@ -127,7 +127,11 @@ __device__ __forceinline__ void gelu_tab_to_lds(const float *tab, char *dst, int
 // it and hide a broken activation behind a finite, wrong embedding): v_med3_f32 + v_cmp_u_f32 + v_cndmask per element,
 // bf16 encoders only, in epilogues that are not VALU-bound.
 __device__ __forceinline__ float sat_f16_1(float v) {
-    const float c = __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);
+    // one scalar constant, used twice (negated once): as __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f) one of the two
+    // bounds lives in a VECTOR register for the whole kernel (a VOP3 reads one scalar), which made this instantiation
+    // the only one past 224 VGPRs - the allocation step that leaves room for the other stream's LayerNorm (encoder.hip)
+    float c;
+    asm("v_med3_f32 %0, %1, %2, -%2" : "=v"(c) : "v"(v), "s"(65504.0f));
     return __builtin_isnan(v) ? v : c;
 }
 __device__ __forceinline__ f32x2 sat_f16(f32x2 v) { return f32x2{sat_f16_1(v.x), sat_f16_1(v.y)}; }
@@ -714,22 +718,10 @@ __global__ void __launch_bounds__(512, 1) gemm256p_kernel(GemmArgs g) {
 
     int tile = vbid;
     if (tile >= ntiles) return;  // whole workgroup leaves together (grid <= ntiles, so this never splits a barrier)
-    // XCD de-phasing (round 4, developer switch VIDMEM_GEMM_DEPHASE_PCT, off: MEASURED NULL).  Every CU walks tiles of
-    // the same cost from the same start, so all 256 reach their epilogues together and one round's 33 MB of output
-    // stores leave as one burst; the harness ablations price the stores at 97 us of FC1's 931 us launch (the whole
-    // epilogue arithmetic: 33 us).  Starting the eight XCDs an eighth of a tile time apart (the CUs that share operand
-    // panels share an XCD's L2 and stay in phase) was meant to spread that burst: 0 / 50 / 100 / 200 / 400 % of that
-    // stagger gave 954 / 956 / 962 / 971 / 981 us on FC1 and lost on every other shape (projection 239 -> 259 us at
-    // 100 %): the stores' cost is not the lockstep burst.
-    if (g.dephase_ticks != 0) {
-        // > 0: per XCD slot; < 0: a ramp INSIDE every XCD, -ticks per renumbered workgroup (neighbours - which share
-        // operand panels - stay within a fraction of a microsecond of each other, the XCD's 32 bursts spread out)
-        const unsigned long long wait = g.dephase_ticks > 0
-                                            ? (unsigned long long)(blockIdx.x & 7) * g.dephase_ticks
-                                            : (unsigned long long)(vbid % ((int)gridDim.x >> 3 ? (int)gridDim.x >> 3 : 1)) * (-g.dephase_ticks);
-        const unsigned long long t_start = wall_clock64();
-        while (wall_clock64() - t_start < wait) __builtin_amdgcn_s_sleep(16);
-    }
+    // (Round 4 measured two start-delay switches here - per XCD slot and a ramp inside every XCD - null on every shape:
+    // the CUs' tile boundaries spread over more than a tile period by themselves after a few rounds, DESIGN.md 4.2.  The
+    // code is gone: its three live registers took the kernel from 224 to 227 VGPRs, past the allocation step that leaves
+    // 64 registers per SIMD for the low-register LayerNorm of the encoder's other stream, encoder.hip.)
     // LDS behind the staging buffers: [2 bias slots of 1 KiB][8 x 2 KiB epilogue scratch][GELU table].
     // The 256 bias values of a TILE arrive by one LDS-DMA instruction (64 lanes x 16 B, wave 0) in the slot of the
     // tile's parity, issued a whole tile ahead (prologue: tile 0; boundary n: tile n + 1, ahead of the prestage), so the
@@ -751,13 +743,6 @@ __global__ void __launch_bounds__(512, 1) gemm256p_kernel(GemmArgs g) {
     };
     int tcount = 0;   // tiles finished by this workgroup (bias slot = parity)
     stage_bias(tile, 0);
-    if (ABL & 128) {  // ablation: start the workgroups of an XCD in 4 groups, g.P x 10 ns apart (epilogue bursts desynchronised)
-        const int grp = (blockIdx.x >> 3) & 3;
-        const unsigned long long t_start = __builtin_readcyclecounter();
-        (void)t_start;
-        const unsigned long long r0 = wall_clock64();
-        while (wall_clock64() - r0 < (unsigned long long)(grp * g.P)) __builtin_amdgcn_s_sleep(8);
-    }
     set_sources(tile);
     stage_Wa0(0, 0);
     stage_Xb0(0, 0);
@@ -1034,7 +1019,7 @@ int launch_epi(vm_ctx *ctx, const GemmArgs &g, hipStream_t st) {
         VM_LAUNCH_CHECK(ctx);                                                                                     \
         return VM_OK;                                                                                             \
     }
-        ABLP(32) ABLP(64) ABLP(96) ABLP(96 + 16) ABLP(128) ABLP(256)
+        ABLP(32) ABLP(64) ABLP(96) ABLP(96 + 16) ABLP(256)
 #undef ABLP
         if (variant == 1024 + 8) {
             auto k = gemm256p_kernel<VM_F16, EPI, 8>;
@@ -1126,16 +1111,6 @@ int vm_gemm(vm_ctx *ctx, int dtype, const GemmArgs &g, int epi, hipStream_t st) 
     if (a.hm_rows <= 0) a.hm_rows = g.M;
     if (a.hm_stride <= 0) a.hm_stride = 1;
     a.gelu_tab = ctx ? ctx->gelu_tab : nullptr;
-    {   // XCD de-phasing of the persistent kernel: an eighth of one tile's time per XCD slot (gemm256p_kernel).  A tile
-        // is 2 x 256 x 256 x K FLOP at ~3.4 TFLOP/s per CU (what the K loop sustains); launches of fewer than four
-        // rounds of tiles keep the common start (the stagger would be a visible tail).  100 MHz wall-clock ticks.
-        static const long pct = VM_DEV_ENV("GEMM_DEPHASE_PCT", 0);   // measured null (gemm256p_kernel): off
-        const double tile_us = 2.0 * 256 * 256 * g.K / 3.4e6;
-        const double rounds = (double)((g.M + 255) / 256) * (g.N / 256) / (ctx ? ctx->num_cus : 256);
-        a.dephase_ticks = (pct > 0 && rounds >= 4.0) ? (int)(tile_us * 100.0 / 8.0 * pct / 100.0) : 0;
-        static const long ramp = VM_DEV_ENV("GEMM_DEPHASE_RAMP", 0);   // 100 MHz ticks per workgroup inside an XCD
-        if (ramp > 0 && rounds >= 4.0) a.dephase_ticks = -(int)ramp;
-    }
     if (epi == EPI_GELU16 && !a.gelu_tab) return vm_fail(ctx, VM_ERR_INVALID, "vm_gemm: GELU epilogue needs a context");
     {   // feature-tile groups of the persistent 256 x 256 kernel (gemm256p_kernel, "Tile order")
         // weight bytes an XCD's L2 keeps beside the streams; 0 = off

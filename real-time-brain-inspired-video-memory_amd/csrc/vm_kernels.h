@@ -32,7 +32,6 @@ struct GemmArgs {
     int fgroup;         // set by vm_gemm: feature tiles per group of the persistent kernel's tile order (0 = all)
     int explicit_zero;  // set by vm_gemm (developer A/B, VIDMEM_GEMM_ZERO=1): clear accumulators per tile instead of C = 0
     const float *gelu_tab;  // set by vm_gemm: the context's erf-GELU table (EPI_GELU16 only)
-    int dephase_ticks;      // set by vm_gemm: start delay per XCD slot of the persistent kernel, 100 MHz ticks (0 = none)
     unsigned long long *stamps;  // developer harness only (-DVM_GEMM_ABLATE builds read it): [grid][64][2] 100 MHz wall-clock
                                  // stamps of the persistent kernel's tile boundaries (K loop done / epilogue issued); else null
 };
