@@ -777,21 +777,42 @@ def main():
 
         th = threading.Thread(target=producer, daemon=True)
         th.start()
-        lat_f = []
+        lat_f, parts = [], []
+        # The consumer loop of a latency-bound feed: two event pairs created ONCE and reused (a chunk is synchronised
+        # before the next is taken), and Python's cyclic garbage collector off for the duration - round 4's breakdown
+        # traced the feed's rare 10-70 ms outliers to the host's submit step (an event created per chunk + a
+        # collection pause), never to the device (2.50 ms per replay, every chunk)
+        import gc
+        ev_ring = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(2)]
+        gc.collect()
+        gc.disable()
         while True:
             t_arr = ready.get(timeout=120.0)
             if t_arr is None:
                 break
+            t_pop = time.perf_counter()              # the consumer thread is awake and holds the chunk
             ticket = stager.commit(16)
             slot_free.release()
+            ev_a, ev = ev_ring[len(lat_f) & 1]
+            ev_a.record(sess.stream)
             sess.push_staged(ticket)
-            ev = torch.cuda.Event()
             ev.record(sess.stream)
+            t_sub = time.perf_counter()              # H2D and replay are queued
             ev.synchronize()
-            lat_f.append((time.perf_counter() - t_arr) * 1e3)
+            t_done = time.perf_counter()
+            lat_f.append((t_done - t_arr) * 1e3)
+            # where a chunk's latency went: waking the consumer, queueing the work, waiting for the device - and, on
+            # the device's own clock, the replay stream from "previous work done" to "results ready" (H2D wait included)
+            parts.append(((t_pop - t_arr) * 1e3, (t_sub - t_pop) * 1e3, (t_done - t_sub) * 1e3, ev_a.elapsed_time(ev)))
         th.join()
+        gc.enable()
         feed_redone = sess.uncertified_last_push
         lf = sorted(lat_f[20:])
+        order = sorted(range(20, len(lat_f)), key=lambda i: lat_f[i])
+        names = ("consumer_wakeup_ms", "host_submit_ms", "host_wait_for_device_ms", "device_stream_ms")
+
+        def part_row(i):
+            return dict({"latency_ms": round(lat_f[i], 3), "chunk": i}, **{n: round(v, 3) for n, v in zip(names, parts[i])})
 
         def pct(v, p):
             return v[min(len(v) - 1, int(len(v) * p))]
@@ -808,6 +829,12 @@ def main():
                 "p50_ms": pct(lf, 0.50), "p99_ms": pct(lf, 0.99), "p99_9_ms": pct(lf, 0.999), "max_ms": lf[-1],
                 "deadline_ms": 33.0, "missed_deadlines": sum(1 for v in lf if v > 33.0),
                 "uncertified_queries_redone_last_push": feed_redone,
+                "breakdown": {
+                    "what": "host clock: chunk ready -> consumer thread awake (queue + GIL) -> H2D and replay queued -> "
+                            "replay's event done; device_stream_ms = the same replay between two events on its stream",
+                    "median_chunk": part_row(order[len(order) // 2]),
+                    "slowest_chunks": [part_row(i) for i in order[-3:][::-1]],
+                },
             },
             "budget_ms": 33.0,
         }
