@@ -373,7 +373,9 @@ int vm_resid_layernorm(vm_ctx *ctx, int dtype, float *x32, const uint16_t *delta
     const int blocks = (rows + 4 * RPW - 1) / (4 * RPW);
     if (H % 256 != 0) return vm_fail(ctx, VM_ERR_UNSUPPORTED, "row width %d", H);
     vm_prof_scope prof(ctx, VM_PROF_LAYERNORM, st);
-    if (lowreg) {   // two-stream mode: the variant that fits beside the persistent GEMM (always the streaming policy)
+    static const int lowreg_env = (int)VM_DEV_ENV("LN_LOWREG", 1);   // developer A/B: 0 = the ordinary kernel on two streams as well
+    // (round 4, three alternating pairs: ViT-B/16 26.78-26.84 k against 27.23-27.25 k frames/s with this one, CLIP-L 2,691 / 2,804)
+    if (lowreg != 0 && lowreg_env != 0) {   // two-stream mode: the variant that fits beside the persistent GEMM (always the streaming policy)
         const int blk = (rows + 3) / 4;
 #define RLNL(V)                                                                                                          \
     if (dtype == VM_F16)                                                                                                 \
